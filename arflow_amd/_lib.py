@@ -1,0 +1,71 @@
+"""ctypes binding of libarflow_hip.so (the C ABI declared in include/arflow_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing the ops
+raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C arflow_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libarflow_hip.so')
+
+c_fp = ctypes.c_void_p  # device pointers travel as integers
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_f = ctypes.c_float
+
+# name -> argtypes, exactly the prototypes of include/arflow_hip.h
+PROTOTYPES = {
+    'arflow_abi_version': [],
+    'arflow_corr_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_corr_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_warp_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_warp_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_splat_map': [c_fp, c_fp, c_i, c_i, c_i, c_l, c_i, c_fp],
+    'arflow_coord_mask': [c_fp, c_fp, c_i, c_i, c_i, c_l, c_i, c_fp],
+    'arflow_occ_bidir': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_l, c_l, c_f, c_f, c_fp],
+    'arflow_census_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_census_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_photo_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_photo_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_smooth_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_l, c_f, c_f, c_i, c_i, c_i, c_fp],
+    'arflow_smooth_bwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_l, c_f, c_f, c_i, c_i, c_i, c_fp],
+    'arflow_down4': [c_fp, c_fp, c_i, c_i, c_i, c_fp],
+    'arflow_up4_clamp_mul': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class ArflowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ArflowHipError(
+            'libarflow_hip.so not found at %s: the HIP extension is not built and there is no CPU '
+            'fallback.  Run `make -C arflow_amd/csrc` (or __graft_entry__.build()).' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_i
+    lib.arflow_strerror.argtypes = [c_i]
+    lib.arflow_strerror.restype = ctypes.c_char_p
+    if lib.arflow_abi_version() != ABI_VERSION:
+        raise ArflowHipError('libarflow_hip.so ABI %d != expected %d; rebuild' % (lib.arflow_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().arflow_strerror(code)
+        raise ArflowHipError('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', code))

@@ -1,0 +1,36 @@
+"""Drop-in ``Correlation`` module backed by the gfx950 cost-volume kernels.
+
+Swap point in the reference: the import pair at models/pwclite.py:6-7 (README.md:30).  Accepts
+the keyword set every call site uses (models/pwclite.py:124-126, models/pwclite_uflow.py:147-149):
+``Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)``.
+"""
+import torch.nn as nn
+
+from . import functional as AF
+
+
+class Correlation(nn.Module):
+    def __init__(self, pad_size=None, kernel_size=1, max_displacement=4, stride1=1, stride2=1,
+                 corr_multiply=1, **kwargs):
+        super().__init__()
+        if pad_size is None:
+            pad_size = max_displacement
+        # models/correlation_native.py:7 swallows these arguments and always computes the
+        # (pad=d, kernel=1, stride=1) volume; the CUDA extension generalises them but no model uses
+        # anything else.  Refuse rather than silently compute something different.
+        if (kernel_size, stride1, stride2) != (1, 1, 1) or pad_size != max_displacement:
+            raise NotImplementedError('only kernel_size=1, stride1=stride2=1, pad_size=max_displacement is supported')
+        self.max_displacement = int(max_displacement)
+        self.output_dim = 2 * self.max_displacement + 1
+        self.pad_size = self.max_displacement
+
+    def forward(self, x1, x2):
+        return AF.correlation(x1, x2, self.max_displacement)
+
+
+def compute_cost_volume(features1, features2, max_displacement):
+    """models/uflow_model.py:53-92 (same arithmetic as Correlation, NCHW)."""
+    _, _, height, _ = features1.shape
+    if max_displacement <= 0 or max_displacement >= height:
+        raise ValueError(f'Max displacement of {max_displacement} is too large.')
+    return AF.correlation(features1, features2, max_displacement)

@@ -1,0 +1,96 @@
+// Shared device/host helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/arflow_hip.h"
+
+#define AF_WAVE 64
+
+#define AF_REQUIRE_PTR(p) \
+  do {                    \
+    if ((p) == nullptr) return ARFLOW_ENULL; \
+  } while (0)
+#define AF_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+static inline int af_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ARFLOW_OK : (ARFLOW_ELAUNCH_BASE - (int)e);
+}
+static inline int af_hip_status(hipError_t e) {
+  return e == hipSuccess ? ARFLOW_OK : (ARFLOW_ELAUNCH_BASE - (int)e);
+}
+static inline int af_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Sum over the 64 lanes of a wave; every lane gets the total.
+__device__ __forceinline__ float af_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, AF_WAVE);
+  return v;
+}
+
+// Block-wide sum of NV values per thread, result valid in thread 0.  `scratch` needs
+// NV * (blockDim/64) floats of LDS.  All threads must call.
+template <int NV>
+__device__ __forceinline__ void af_block_sum(float (&v)[NV], float* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = af_wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[k * nw + wave] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += scratch[k * nw + w];
+      v[k] = s;
+    }
+  }
+}
+
+// torch grid_sample un-normalisation (ATen/native/GridSampler.h:27-36).
+__device__ __forceinline__ float af_unnormalize(float g, int size, bool align) {
+  return align ? ((g + 1.f) / 2.f) * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) / 2.f;
+}
+
+// Pixel coordinate sampled for output position p with displacement u, reproducing the reference's
+// fp32 normalise -> un-normalise round trip.
+//   norm 0 (ARFlow flow_warp, utils/warp_utils.py:16-23): g = 2*(p+u)/(n_flow-1) - 1, then
+//           grid_sample's un-normalisation with the SOURCE size and the align flag;
+//   norm 1 (UFlow resample, utils/uflow_utils.py:71-76): g = 2*(p+u)/max(n_src-1,1) - 1, align=True;
+//   norm 2: as 1, but `u` is the absolute coordinate (resample(source, coords) called directly).
+// *dcoord receives d(coordinate)/d(u).
+__device__ __forceinline__ float af_sample_coord(float p, float u, int n_flow, int n_src, int norm,
+                                                 bool align, float* dcoord) {
+  if (norm != ARFLOW_NORM_ARFLOW) {
+    const float den = (float)(n_src - 1 > 1 ? n_src - 1 : 1);
+    const float pos = norm == ARFLOW_NORM_UFLOW_ABS ? u : p + u;  // ABS: `u` already is the coordinate
+    const float g = 2.0f * pos / den - 1.0f;
+    *dcoord = (2.0f / den) * ((float)(n_src - 1) / 2.f);
+    return ((g + 1.f) / 2.f) * (float)(n_src - 1);
+  }
+  const float den = (float)(n_flow - 1);
+  const float g = 2.0f * (p + u) / den - 1.0f;
+  *dcoord = (2.0f / den) * (align ? (float)(n_src - 1) / 2.f : (float)n_src / 2.f);
+  return af_unnormalize(g, n_src, align);
+}
+
+// border padding: clamp to [0,size-1]; the coordinate gradient is zeroed at/over the border
+// (ATen/native/GridSampler.h:58-83).
+__device__ __forceinline__ float af_clip_border(float c, int size, float* dmul) {
+  if (c <= 0.f) {
+    *dmul = 0.f;
+    return 0.f;
+  }
+  const float mx = (float)(size - 1);
+  if (c >= mx) {
+    *dmul = 0.f;
+    return mx;
+  }
+  return c;
+}

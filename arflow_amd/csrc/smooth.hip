@@ -1,0 +1,211 @@
+// Edge-aware flow smoothness (1st / 2nd order) forward + backward, and the two resize helpers of
+// the UFlow loss, for gfx950.
+//
+// Reference arithmetic: losses/loss_blocks.py (gradient :87-90, smooth_grad_1st :93-109,
+// smooth_grad_2nd :112-124, penalty_uflow :8-9), losses/uflow_loss.py:56-102 (image_grads,
+// robust_l1 of utils/uflow_utils.py:207-210,337-338), utils/uflow_utils.py:163-204
+// (upsample / downsample, bilinear, align_corners=False).
+//
+// One lane per pixel; every value a lane needs sits within 2 pixels of it, so the neighbouring
+// reads hit L1/L2 and HBM sees each tensor once.  The reference runs ~12 elementwise ATen kernels
+// plus 2 reductions per direction; here it is one launch forward and one backward.
+#include "common.hpp"
+
+namespace {
+
+struct SmoothArgs {
+  const float* flow;
+  const float* img;
+  int Ci, H, W;
+  long fbs;
+  float fscale, alpha;
+  int order, wmode, penalty;
+};
+
+__device__ __forceinline__ float pen(float v, int penalty) {
+  return penalty == 0 ? fabsf(v) : sqrtf(fmaf(v, v, 1e-6f));
+}
+__device__ __forceinline__ float dpen(float v, int penalty) {
+  if (penalty == 0) return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+  return v / sqrtf(fmaf(v, v, 1e-6f));
+}
+
+// edge weight for the x-difference anchored at (y,x); caller guarantees validity.
+__device__ __forceinline__ float edge_wx(const SmoothArgs& a, const float* ib, int y, int x) {
+  const int xa = a.order == 1 ? x + 1 : x + 2;
+  const int xb = a.order == 1 ? x : (a.wmode == 0 ? x + 1 : x);
+  const long cs = (long)a.H * a.W;
+  float s = 0.f;
+  for (int c = 0; c < a.Ci; ++c) s += fabsf(ib[c * cs + (long)y * a.W + xa] - ib[c * cs + (long)y * a.W + xb]);
+  return __expf(-(s / (float)a.Ci) * a.alpha);
+}
+__device__ __forceinline__ float edge_wy(const SmoothArgs& a, const float* ib, int y, int x) {
+  const int ya = a.order == 1 ? y + 1 : y + 2;
+  const int yb = a.order == 1 ? y : (a.wmode == 0 ? y + 1 : y);
+  const long cs = (long)a.H * a.W;
+  float s = 0.f;
+  for (int c = 0; c < a.Ci; ++c) s += fabsf(ib[c * cs + (long)ya * a.W + x] - ib[c * cs + (long)yb * a.W + x]);
+  return __expf(-(s / (float)a.Ci) * a.alpha);
+}
+// flow differences anchored at (y,x)
+__device__ __forceinline__ float diff_x(const SmoothArgs& a, const float* f, int y, int x) {
+  const float* r = f + (long)y * a.W + x;
+  return a.order == 1 ? (r[1] - r[0]) * a.fscale : ((r[2] - r[1]) - (r[1] - r[0])) * a.fscale;
+}
+__device__ __forceinline__ float diff_y(const SmoothArgs& a, const float* f, int y, int x) {
+  const float* r = f + (long)y * a.W + x;
+  const int W = a.W;
+  return a.order == 1 ? (r[W] - r[0]) * a.fscale : ((r[2 * W] - r[W]) - (r[W] - r[0])) * a.fscale;
+}
+
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __restrict__ sums) {
+  __shared__ float red[2 * 4];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  const int o = a.order;
+  float part[2] = {0.f, 0.f};
+  if (x < a.W) {
+    const float* ib = a.img + (long)b * a.Ci * a.H * a.W;
+    const float* fb = a.flow + (long)b * a.fbs;
+    const long cs = (long)a.H * a.W;
+    if (x < a.W - o) {
+      const float w = edge_wx(a, ib, y, x);
+      part[0] = w * (pen(diff_x(a, fb, y, x), a.penalty) + pen(diff_x(a, fb + cs, y, x), a.penalty));
+    }
+    if (y < a.H - o) {
+      const float w = edge_wy(a, ib, y, x);
+      part[1] = w * (pen(diff_y(a, fb, y, x), a.penalty) + pen(diff_y(a, fb + cs, y, x), a.penalty));
+    }
+  }
+  af_block_sum<2>(part, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums, part[0]);
+    atomicAdd(sums + 1, part[1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void smooth_bwd_kernel(SmoothArgs a, const float* __restrict__ coef,
+                                                        float* __restrict__ gflow) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= a.W) return;
+  const int o = a.order;
+  const float* ib = a.img + (long)b * a.Ci * a.H * a.W;
+  const float* fb = a.flow + (long)b * a.fbs;
+  const long cs = (long)a.H * a.W;
+  const float cx = coef[0] * a.fscale, cy = coef[1] * a.fscale;
+  float g[2] = {0.f, 0.f};
+  // pixel (y,x) enters the difference anchored at x-k with stencil coefficient st[k]
+  // order 1: {-1, +1}; order 2: {+1, -2, +1}
+  const float st1[2] = {-1.f, 1.f};
+  const float st2[3] = {1.f, -2.f, 1.f};
+  for (int k = 0; k <= o; ++k) {
+    const float s = o == 1 ? st1[k] : st2[k];
+    const int xa = x - k;
+    if (xa >= 0 && xa < a.W - o) {
+      const float w = edge_wx(a, ib, y, xa) * s * cx;
+      g[0] = fmaf(w, dpen(diff_x(a, fb, y, xa), a.penalty), g[0]);
+      g[1] = fmaf(w, dpen(diff_x(a, fb + cs, y, xa), a.penalty), g[1]);
+    }
+    const int ya = y - k;
+    if (ya >= 0 && ya < a.H - o) {
+      const float w = edge_wy(a, ib, ya, x) * s * cy;
+      g[0] = fmaf(w, dpen(diff_y(a, fb, ya, x), a.penalty), g[0]);
+      g[1] = fmaf(w, dpen(diff_y(a, fb + cs, ya, x), a.penalty), g[1]);
+    }
+  }
+  float* go = gflow + (long)b * 2 * cs + (long)y * a.W + x;
+  go[0] = g[0];
+  go[cs] = g[1];
+}
+
+// bilinear x1/4, align_corners=False on a multiple-of-4 grid: source coordinate of output i is
+// 4i+1.5, i.e. the mean of pixels 4i+1 and 4i+2 in each axis.
+__global__ __launch_bounds__(256) void down4_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                   int H, int W) {
+  const int h = H / 4, w = W / 4;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const float* p = in + (long)blockIdx.z * H * W + (long)(4 * y + 1) * W + 4 * x + 1;
+  // F.interpolate evaluates (1-ly)*((1-lx)*a + lx*b) + ly*((1-lx)*c + lx*d) with lx = ly = 0.5
+  out[((long)blockIdx.z * h + y) * w + x] = 0.5f * (0.5f * p[0] + 0.5f * p[1]) + 0.5f * (0.5f * p[W] + 0.5f * p[W + 1]);
+}
+
+__global__ __launch_bounds__(256) void up4_clamp_mul_kernel(const float* __restrict__ in,
+                                                           const float* __restrict__ valid,
+                                                           float* __restrict__ out, int h, int w) {
+  const int H = 4 * h, W = 4 * w;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  // torch area_pixel_compute_source_index: max(0.25*(dst+0.5)-0.5, 0)
+  const float sy = fmaxf(0.25f * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.25f * ((float)x + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float* p = in + (long)b * h * w;
+  auto cl = [](float v) { return fminf(fmaxf(v, 0.f), 1.f); };
+  const float v00 = cl(p[(long)y0 * w + x0]), v01 = cl(p[(long)y0 * w + x1]);
+  const float v10 = cl(p[(long)y1 * w + x0]), v11 = cl(p[(long)y1 * w + x1]);
+  float r = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  const long o = ((long)b * H + y) * W + x;
+  if (valid) r *= valid[o];
+  out[o] = r;
+}
+
+int check_smooth(const float* flow, const float* img, int B, int Ci, int H, int W, long fbs, int order,
+                 int wmode, int penalty) {
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(img);
+  AF_REQUIRE(B > 0 && Ci > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(fbs >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(order == 1 || order == 2, ARFLOW_EPARAM);
+  AF_REQUIRE(wmode == 0 || wmode == 1, ARFLOW_EPARAM);
+  AF_REQUIRE(penalty == 0 || penalty == 1, ARFLOW_EPARAM);
+  return ARFLOW_OK;
+}
+
+}  // namespace
+
+extern "C" int arflow_smooth_fwd(const float* flow, const float* img, float* sums, int B, int Ci, int H,
+                                 int W, long flow_bstride, float flow_scale, float alpha, int order,
+                                 int wmode, int penalty, arflow_stream_t stream) {
+  int rc = check_smooth(flow, img, B, Ci, H, W, flow_bstride, order, wmode, penalty);
+  if (rc) return rc;
+  AF_REQUIRE_PTR(sums);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), st);
+  if (e != hipSuccess) return af_hip_status(e);
+  SmoothArgs a{flow, img, Ci, H, W, flow_bstride, flow_scale, alpha, order, wmode, penalty};
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, st, a, sums);
+  return af_launch_status();
+}
+
+extern "C" int arflow_smooth_bwd(const float* flow, const float* img, const float* coef, float* gflow, int B,
+                                 int Ci, int H, int W, long flow_bstride, float flow_scale, float alpha,
+                                 int order, int wmode, int penalty, arflow_stream_t stream) {
+  int rc = check_smooth(flow, img, B, Ci, H, W, flow_bstride, order, wmode, penalty);
+  if (rc) return rc;
+  AF_REQUIRE_PTR(coef);
+  AF_REQUIRE_PTR(gflow);
+  SmoothArgs a{flow, img, Ci, H, W, flow_bstride, flow_scale, alpha, order, wmode, penalty};
+  hipLaunchKernelGGL(smooth_bwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, a,
+                     coef, gflow);
+  return af_launch_status();
+}
+
+extern "C" int arflow_down4(const float* in, float* out, int planes, int H, int W, arflow_stream_t stream) {
+  AF_REQUIRE_PTR(in);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(planes > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && planes <= 65535, ARFLOW_ESHAPE);
+  hipLaunchKernelGGL(down4_kernel, dim3(af_cdiv(W / 4, 256), H / 4, planes), dim3(256), 0, (hipStream_t)stream,
+                     in, out, H, W);
+  return af_launch_status();
+}
+
+extern "C" int arflow_up4_clamp_mul(const float* in, const float* valid, float* out, int B, int h, int w,
+                                    arflow_stream_t stream) {
+  AF_REQUIRE_PTR(in);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && h > 0 && w > 0 && B <= 65535 && 4 * h <= 65535, ARFLOW_ESHAPE);
+  hipLaunchKernelGGL(up4_clamp_mul_kernel, dim3(af_cdiv(4 * w, 256), 4 * h, B), dim3(256), 0,
+                     (hipStream_t)stream, in, valid, out, h, w);
+  return af_launch_status();
+}

@@ -1,0 +1,309 @@
+// Bilinear flow warp (forward / backward), forward-splat occlusion maps and coordinate masks for
+// gfx950.  Reference arithmetic: utils/warp_utils.py (flow_warp :83-90, get_corresponding_map
+// :26-80, get_occu_mask_bidirection :93-100, border_mask :119-134), utils/uflow_utils.py
+// (flow_to_warp :6-32, mask_invalid :35-50, resample :53-77, compute_range_map :80-160) and torch's
+// grid_sample (ATen/native/GridSampler.h) which the reference calls.
+//
+// Layout: one lane per output pixel, consecutive lanes along x, so flow reads, every output
+// channel plane and (for small displacements) the four source taps are coalesced.  Coordinates
+// and bilinear weights are computed once per pixel and reused for all channels.  HBM traffic is
+// the compulsory 4*px*(2C+2) bytes forward, 4*px*(3C+4) backward.
+#include "common.hpp"
+
+namespace {
+
+struct Taps {
+  int x0, y0;           // north-west corner
+  float wx0, wx1, wy0, wy1;
+  bool vx0, vx1, vy0, vy1;  // corner inside the source
+  float dx, dy;         // d coord / d flow (0 where border clamping is active)
+};
+
+__device__ __forceinline__ Taps make_taps(float px, float py, float u, float v, int H, int W, int Hs,
+                                          int Ws, int pad, bool align, int norm) {
+  Taps t;
+  float ix = af_sample_coord(px, u, W, Ws, norm, align, &t.dx);
+  float iy = af_sample_coord(py, v, H, Hs, norm, align, &t.dy);
+  if (pad == ARFLOW_PAD_BORDER) {
+    ix = af_clip_border(ix, Ws, &t.dx);
+    iy = af_clip_border(iy, Hs, &t.dy);
+  }
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.wx1 = ix - fx;
+  t.wx0 = (fx + 1.f) - ix;
+  t.wy1 = iy - fy;
+  t.wy0 = (fy + 1.f) - iy;
+  // comparisons in float first: NaN / huge coordinates fall out as "outside"
+  t.vx0 = fx >= 0.f && fx <= (float)(Ws - 1);
+  t.vx1 = fx + 1.f >= 0.f && fx + 1.f <= (float)(Ws - 1);
+  t.vy0 = fy >= 0.f && fy <= (float)(Hs - 1);
+  t.vy1 = fy + 1.f >= 0.f && fy + 1.f <= (float)(Hs - 1);
+  t.x0 = (t.vx0 || t.vx1) ? (int)fx : 0;
+  t.y0 = (t.vy0 || t.vy1) ? (int)fy : 0;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ src,
+                                                       const float* __restrict__ flow,
+                                                       float* __restrict__ out, float* __restrict__ valid,
+                                                       int C, int Hs, int Ws, int H, int W, long fbs,
+                                                       int pad, int align, int norm) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const float* fb = flow + (long)b * fbs + (long)y * W + x;
+  const float u = fb[0], v = fb[(long)H * W];
+  const Taps t = make_taps((float)x, (float)y, u, v, H, W, Hs, Ws, pad, align != 0, norm);
+  if (valid) {
+    const bool abs_in = norm == ARFLOW_NORM_UFLOW_ABS;
+    const float cx = abs_in ? u : (float)x + u, cy = abs_in ? v : (float)y + v;
+    valid[((long)b * H + y) * W + x] =
+        (cx >= 0.f && cx <= (float)(W - 1) && cy >= 0.f && cy <= (float)(H - 1)) ? 1.f : 0.f;
+  }
+  const float wnw = t.wx0 * t.wy0, wne = t.wx1 * t.wy0, wsw = t.wx0 * t.wy1, wse = t.wx1 * t.wy1;
+  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
+  const long o00 = (long)t.y0 * Ws + t.x0;
+  const long ss = (long)Hs * Ws, os = (long)H * W;
+  const float* sp = src + (long)b * C * ss;
+  float* op = out + (long)b * C * os + (long)y * W + x;
+#pragma unroll 4
+  for (int c = 0; c < C; ++c) {
+    const float* s = sp + c * ss + o00;
+    float r = 0.f;
+    if (bnw) r = s[0] * wnw;
+    if (bne) r = fmaf(s[1], wne, r);
+    if (bsw) r = fmaf(s[Ws], wsw, r);
+    if (bse) r = fmaf(s[Ws + 1], wse, r);
+    op[c * os] = r;
+  }
+}
+
+// gsrc: 4-tap atomic scatter (pre-zeroed); gflow: per-pixel reduction over channels.
+template <bool WITH_SRC, bool WITH_FLOW>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ gout,
+                                                       const float* __restrict__ src,
+                                                       const float* __restrict__ flow,
+                                                       float* __restrict__ gsrc, float* __restrict__ gflow,
+                                                       int C, int Hs, int Ws, int H, int W, long fbs,
+                                                       int pad, int align, int norm) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const float* fb = flow + (long)b * fbs + (long)y * W + x;
+  const Taps t = make_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
+  const float wnw = t.wx0 * t.wy0, wne = t.wx1 * t.wy0, wsw = t.wx0 * t.wy1, wse = t.wx1 * t.wy1;
+  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
+  const long o00 = (long)t.y0 * Ws + t.x0;
+  const long ss = (long)Hs * Ws, os = (long)H * W;
+  const float* sp = src + (long)b * C * ss;
+  float* gp = WITH_SRC ? gsrc + (long)b * C * ss : nullptr;
+  const float* gop = gout + (long)b * C * os + (long)y * W + x;
+  float gix = 0.f, giy = 0.f;
+#pragma unroll 2
+  for (int c = 0; c < C; ++c) {
+    const float g = gop[c * os];
+    if (WITH_SRC) {
+      float* d = gp + c * ss + o00;
+      if (bnw) atomicAdd(d, g * wnw);
+      if (bne) atomicAdd(d + 1, g * wne);
+      if (bsw) atomicAdd(d + Ws, g * wsw);
+      if (bse) atomicAdd(d + Ws + 1, g * wse);
+    }
+    if (WITH_FLOW) {
+      const float* s = sp + c * ss + o00;
+      const float nw = bnw ? s[0] : 0.f, ne = bne ? s[1] : 0.f;
+      const float sw = bsw ? s[Ws] : 0.f, se = bse ? s[Ws + 1] : 0.f;
+      // d out / d ix = (ne-nw)*wy0 + (se-sw)*wy1 ; d out / d iy = (sw-nw)*wx0 + (se-ne)*wx1
+      gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
+      giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
+    }
+  }
+  if (WITH_FLOW) {
+    float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
+    gf[0] = gix * t.dx;
+    gf[os] = giy * t.dy;
+  }
+}
+
+// forward splat of the 4 bilinear weights of every pixel's target position
+__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ flow, float* __restrict__ out,
+                                                    int H, int W, long fbs, int variant) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const float* fb = flow + (long)b * fbs + (long)y * W + x;
+  const bool abs_in = (variant & ARFLOW_COORDS_ABS) != 0;
+  const float cx = abs_in ? fb[0] : (float)x + fb[0], cy = abs_in ? fb[(long)H * W] : (float)y + fb[(long)H * W];
+  const float fx = floorf(cx), fy = floorf(cy);
+  float* ob = out + (long)b * H * W;
+  if ((variant & 1) == 0) {
+    // compute_range_map: weights from the fractional offset, out-of-image taps dropped
+    const float ox = cx - fx, oy = cy - fy;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const float yi = fy + di, xj = fx + dj;
+        if (yi >= 0.f && yi < (float)H && xj >= 0.f && xj < (float)W) {
+          const float w = (di ? oy : 1.f - oy) * (dj ? ox : 1.f - ox);
+          atomicAdd(ob + (long)(int)yi * W + (int)xj, w);
+        }
+      }
+  } else {
+    // get_corresponding_map: indices clamped into the image, weight (1-|x-xi|)(1-|y-yi|) with the
+    // CLAMPED corner, zero when the un-clamped corner was outside
+    const float xw = (float)(W - 1), yh = (float)(H - 1);
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const float yr = fy + di, xr = fx + dj;
+        const float yc = fminf(fmaxf(yr, 0.f), yh), xc = fminf(fmaxf(xr, 0.f), xw);
+        if (yc == yr && xc == xr) {
+          const float w = (1.f - fabsf(cx - xc)) * (1.f - fabsf(cy - yc));
+          atomicAdd(ob + (long)(int)yc * W + (int)xc, w);
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void coord_mask_kernel(const float* __restrict__ flow,
+                                                         float* __restrict__ out, int H, int W, long fbs,
+                                                         int mode) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const float* fb = flow + (long)b * fbs + (long)y * W + x;
+  const bool abs_in = (mode & ARFLOW_COORDS_ABS) != 0;
+  const float cx = abs_in ? fb[0] : (float)x + fb[0], cy = abs_in ? fb[(long)H * W] : (float)y + fb[(long)H * W];
+  const float xw = (float)(W - 1), yh = (float)(H - 1);
+  const bool ok = (mode & 1) == 0 ? (cx >= 0.f && cx <= xw && cy >= 0.f && cy <= yh)
+                            : (cx > 0.f && cx < xw && cy > 0.f && cy < yh);
+  out[((long)b * H + y) * W + x] = ok ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void occ_bidir_kernel(const float* __restrict__ f12,
+                                                        const float* __restrict__ f21,
+                                                        float* __restrict__ out, int H, int W, long bs12,
+                                                        long bs21, float scale, float bias) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const long os = (long)H * W;
+  const float* a = f12 + (long)b * bs12 + (long)y * W + x;
+  const float u = a[0], v = a[os];
+  const Taps t = make_taps((float)x, (float)y, u, v, H, W, H, W, ARFLOW_PAD_ZEROS, true, ARFLOW_NORM_ARFLOW);
+  const float wnw = t.wx0 * t.wy0, wne = t.wx1 * t.wy0, wsw = t.wx0 * t.wy1, wse = t.wx1 * t.wy1;
+  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
+  const float* s = f21 + (long)b * bs21 + (long)t.y0 * W + t.x0;
+  float w2[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float* sc = s + c * os;
+    float r = 0.f;
+    if (bnw) r = sc[0] * wnw;
+    if (bne) r = fmaf(sc[1], wne, r);
+    if (bsw) r = fmaf(sc[W], wsw, r);
+    if (bse) r = fmaf(sc[W + 1], wse, r);
+    w2[c] = r;
+  }
+  const float dx = u + w2[0], dy = v + w2[1];
+  const float mag = (u * u + v * v) + (w2[0] * w2[0] + w2[1] * w2[1]);
+  out[((long)b * H + y) * W + x] = (dx * dx + dy * dy) > (scale * mag + bias) ? 1.f : 0.f;
+}
+
+inline dim3 pixel_grid(int B, int H, int W, int bx) { return dim3(af_cdiv(W, bx), H, B); }
+inline int pick_bx(int W) { return W >= 192 ? 256 : (W >= 96 ? 128 : 64); }
+
+}  // namespace
+
+extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, float* valid, int B, int C,
+                               int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode,
+                               int align_corners, int norm_mode, arflow_stream_t stream) {
+  AF_REQUIRE_PTR(src);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+  const int bx = pick_bx(W);
+  hipLaunchKernelGGL(warp_fwd_kernel, pixel_grid(B, H, W, bx), dim3(bx), 0, (hipStream_t)stream, src, flow,
+                     out, valid, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  return af_launch_status();
+}
+
+extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float* flow, float* gsrc,
+                               float* gflow, int B, int C, int Hs, int Ws, int H, int W, long flow_bstride,
+                               int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {
+  AF_REQUIRE_PTR(gout);
+  AF_REQUIRE_PTR(src);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+  if (!gsrc && !gflow) return ARFLOW_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (gsrc) {
+    hipError_t e = hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * C * Hs * Ws, st);
+    if (e != hipSuccess) return af_hip_status(e);
+  }
+  const int bx = pick_bx(W);
+  const dim3 grid = pixel_grid(B, H, W, bx);
+  if (gsrc && gflow)
+    hipLaunchKernelGGL((warp_bwd_kernel<true, true>), grid, dim3(bx), 0, st, gout, src, flow, gsrc, gflow, C,
+                       Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  else if (gsrc)
+    hipLaunchKernelGGL((warp_bwd_kernel<true, false>), grid, dim3(bx), 0, st, gout, src, flow, gsrc, gflow, C,
+                       Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  else
+    hipLaunchKernelGGL((warp_bwd_kernel<false, true>), grid, dim3(bx), 0, st, gout, src, flow, gsrc, gflow, C,
+                       Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  return af_launch_status();
+}
+
+extern "C" int arflow_splat_map(const float* flow, float* out, int B, int H, int W, long flow_bstride,
+                                int variant, arflow_stream_t stream) {
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(variant >= 0 && variant <= 3, ARFLOW_EPARAM);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * H * W, st);
+  if (e != hipSuccess) return af_hip_status(e);
+  const int bx = pick_bx(W);
+  hipLaunchKernelGGL(splat_kernel, pixel_grid(B, H, W, bx), dim3(bx), 0, st, flow, out, H, W, flow_bstride,
+                     variant);
+  return af_launch_status();
+}
+
+extern "C" int arflow_coord_mask(const float* flow, float* out, int B, int H, int W, long flow_bstride,
+                                 int mode, arflow_stream_t stream) {
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(mode >= 0 && mode <= 3, ARFLOW_EPARAM);
+  const int bx = pick_bx(W);
+  hipLaunchKernelGGL(coord_mask_kernel, pixel_grid(B, H, W, bx), dim3(bx), 0, (hipStream_t)stream, flow, out,
+                     H, W, flow_bstride, mode);
+  return af_launch_status();
+}
+
+extern "C" int arflow_occ_bidir(const float* flow12, const float* flow21, float* out, int B, int H, int W,
+                                long bstride12, long bstride21, float scale, float bias,
+                                arflow_stream_t stream) {
+  AF_REQUIRE_PTR(flow12);
+  AF_REQUIRE_PTR(flow21);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(bstride12 >= 2L * H * W && bstride21 >= 2L * H * W, ARFLOW_ESHAPE);
+  const int bx = pick_bx(W);
+  hipLaunchKernelGGL(occ_bidir_kernel, pixel_grid(B, H, W, bx), dim3(bx), 0, (hipStream_t)stream, flow12,
+                     flow21, out, H, W, bstride12, bstride21, scale, bias);
+  return af_launch_status();
+}

@@ -1,0 +1,351 @@
+"""torch.autograd.Function wrappers over the C ABI (libarflow_hip.so).
+
+Every op here runs ONLY on CUDA(ROCm) fp32 tensors through the hand-written gfx950 kernels; a CPU
+tensor, a wrong dtype or a missing library raises.  Outputs are allocated with the torch caching
+allocator and kernels are enqueued on ``torch.cuda.current_stream()`` -- no synchronisation.
+"""
+import torch
+
+from . import _lib
+
+PAD = {'zeros': 0, 'border': 1}
+NORM_ARFLOW, NORM_UFLOW = 0, 1
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.ArflowHipError('arflow_amd ops run on the GPU only (got a %s tensor); there is no CPU '
+                                      'fallback -- the CPU oracle lives in oracle/ and is test-only' % t.device)
+        if t.dtype != torch.float32:
+            raise _lib.ArflowHipError('arflow_amd ops are fp32 only (got %s)' % t.dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _flow_view(flow):
+    """Return (tensor, batch_stride) so that a [B,2,H,W] slice of a wider tensor is used in place."""
+    B, two, H, W = flow.shape
+    assert two == 2, 'flow must have 2 channels'
+    st = flow.stride()
+    if st[3] == 1 and st[2] == W and st[1] == H * W and (B == 1 or st[0] >= 2 * H * W):
+        return flow, (st[0] if B > 1 else 2 * H * W)
+    flow = flow.contiguous()
+    return flow, 2 * H * W
+
+
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+# ------------------------------------------------------------------------------------------------
+class CorrelationFunction(torch.autograd.Function):
+    """Cost volume; mirrors CorrelationFunction of models/correlation_package/correlation.py:6-44
+    (there an instance-style Function unusable on modern torch) with the arithmetic of
+    models/correlation_native.py:13-23."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, max_displacement):
+        _need_gpu(x1, x2)
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        if x1.shape != x2.shape or x1.dim() != 4:
+            raise ValueError('correlation expects two [B,C,H,W] tensors of equal shape')
+        B, C, H, W = x1.shape
+        d = int(max_displacement)
+        out = torch.empty(B, (2 * d + 1) ** 2, H, W, device=x1.device, dtype=torch.float32)
+        with torch.cuda.device_of(x1):
+            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, W, d, _stream())
+        ctx.save_for_backward(x1, x2)
+        ctx.d = d
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x1, x2 = ctx.saved_tensors
+        B, C, H, W = x1.shape
+        gout = gout.contiguous()
+        g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device_of(x1):
+            _call('arflow_corr_bwd', _p(gout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, W, ctx.d, _stream())
+        return g1, g2, None
+
+
+def correlation(x1, x2, max_displacement=4):
+    return CorrelationFunction.apply(x1, x2, max_displacement)
+
+
+# ------------------------------------------------------------------------------------------------
+class WarpFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, flow, pad, align_corners, norm):
+        _need_gpu(src, flow)
+        src = src.contiguous()
+        flow, fbs = _flow_view(flow)
+        B, C, Hs, Ws = src.shape
+        _, _, H, W = flow.shape
+        if flow.shape[0] != B:
+            raise ValueError('batch mismatch between source and flow')
+        out = torch.empty(B, C, H, W, device=src.device, dtype=torch.float32)
+        with torch.cuda.device_of(src):
+            _call('arflow_warp_fwd', _p(src), _p(flow), _p(out), None, B, C, Hs, Ws, H, W, fbs, pad,
+                  int(bool(align_corners)), norm, _stream())
+        ctx.save_for_backward(src, flow)
+        ctx.cfg = (pad, int(bool(align_corners)), norm, fbs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, flow = ctx.saved_tensors
+        pad, ac, norm, fbs = ctx.cfg
+        B, C, Hs, Ws = src.shape
+        _, _, H, W = flow.shape
+        gout = gout.contiguous()
+        gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty(B, 2, H, W, device=src.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device_of(src):
+            _call('arflow_warp_bwd', _p(gout), _p(src), _p(flow), _p(gsrc), _p(gflow), B, C, Hs, Ws, H, W, fbs,
+                  pad, ac, norm, _stream())
+        return gsrc, gflow, None, None, None
+
+
+def warp(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW):
+    return WarpFunction.apply(src, flow, PAD[pad], align_corners, norm)
+
+
+def _flow_map(name, flow, *extra):
+    _need_gpu(flow)
+    flow, fbs = _flow_view(flow.detach())
+    B, _, H, W = flow.shape
+    out = torch.empty(B, 1, H, W, device=flow.device, dtype=torch.float32)
+    with torch.cuda.device_of(flow):
+        _call(name, _p(flow), _p(out), B, H, W, fbs, *extra, _stream())
+    return out
+
+
+def splat_map(flow, variant):
+    """variant 0: compute_range_map; 1: get_corresponding_map(grid + flow).  No gradient (the
+    reference detaches / thresholds it: losses/uflow_loss.py:43, utils/warp_utils.py:112)."""
+    return _flow_map('arflow_splat_map', flow, int(variant))
+
+
+def coord_mask(flow, mode):
+    """mode 0: mask_invalid(flow_to_warp(flow)); 1: border_mask(flow)."""
+    return _flow_map('arflow_coord_mask', flow, int(mode))
+
+
+def occ_bidir(flow12, flow21, scale=0.01, bias=0.5):
+    _need_gpu(flow12, flow21)
+    f12, s12 = _flow_view(flow12.detach())
+    f21, s21 = _flow_view(flow21.detach())
+    B, _, H, W = f12.shape
+    out = torch.empty(B, 1, H, W, device=f12.device, dtype=torch.float32)
+    with torch.cuda.device_of(f12):
+        _call('arflow_occ_bidir', _p(f12), _p(f21), _p(out), B, H, W, s12, s21, float(scale), float(bias), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+class CensusLossFunction(torch.autograd.Function):
+    """census_loss(image_a, image_b, mask, patch) of utils/uflow_utils.py:282-293 as one fused
+    forward launch and one backward launch.  The mask is treated as a constant (the reference
+    passes a detached mask, losses/uflow_loss.py:43,48)."""
+
+    @staticmethod
+    def forward(ctx, im_a, im_b, mask, patch_size):
+        _need_gpu(im_a, im_b, mask)
+        im_a, im_b, mask = im_a.contiguous(), im_b.contiguous(), mask.contiguous()
+        B, C, H, W = im_a.shape
+        if C != 3 or im_b.shape != im_a.shape or mask.shape != (B, 1, H, W):
+            raise ValueError('census_loss expects [B,3,H,W] images and a [B,1,H,W] mask')
+        r = int(patch_size) // 2
+        sums = torch.empty(2, device=im_a.device, dtype=torch.float32)
+        dham = torch.empty(B, 1, H, W, device=im_a.device, dtype=torch.float32)
+        with torch.cuda.device_of(im_a):
+            _call('arflow_census_fwd', _p(im_a), _p(im_b), _p(mask), None, _p(dham), _p(sums), B, H, W, r, _stream())
+        inv = 1.0 / (sums[1] + 1e-6)
+        ctx.save_for_backward(im_a, im_b, dham, inv)
+        ctx.r = r
+        return sums[0] * inv
+
+    @staticmethod
+    def backward(ctx, gloss):
+        im_a, im_b, dham, inv = ctx.saved_tensors
+        B, _, H, W = im_a.shape
+        scale = (gloss * inv).reshape(1).contiguous()
+        ga = gb = None
+        with torch.cuda.device_of(im_a):
+            if ctx.needs_input_grad[1]:
+                gb = torch.empty_like(im_b)
+                _call('arflow_census_bwd', _p(im_a), _p(im_b), _p(dham), _p(scale), _p(gb), B, H, W, ctx.r, _stream())
+            if ctx.needs_input_grad[0]:
+                ga = torch.empty_like(im_a)  # the distance is symmetric in (a, b)
+                _call('arflow_census_bwd', _p(im_b), _p(im_a), _p(dham), _p(scale), _p(ga), B, H, W, ctx.r, _stream())
+        return ga, gb, None, None
+
+
+class TernaryDistFunction(torch.autograd.Function):
+    """Per-pixel soft census distance (sum over the patch); TernaryLoss core,
+    losses/loss_blocks.py:12-62."""
+
+    @staticmethod
+    def forward(ctx, im_a, im_b, radius):
+        _need_gpu(im_a, im_b)
+        im_a, im_b = im_a.contiguous(), im_b.contiguous()
+        B, C, H, W = im_a.shape
+        if C != 3 or im_b.shape != im_a.shape:
+            raise ValueError('ternary distance expects two [B,3,H,W] images')
+        ham = torch.empty(B, 1, H, W, device=im_a.device, dtype=torch.float32)
+        with torch.cuda.device_of(im_a):
+            _call('arflow_census_fwd', _p(im_a), _p(im_b), None, _p(ham), None, None, B, H, W, int(radius), _stream())
+        ctx.save_for_backward(im_a, im_b)
+        ctx.r = int(radius)
+        return ham
+
+    @staticmethod
+    def backward(ctx, gham):
+        im_a, im_b = ctx.saved_tensors
+        B, _, H, W = im_a.shape
+        gham = gham.contiguous()
+        ga = gb = None
+        with torch.cuda.device_of(im_a):
+            if ctx.needs_input_grad[0]:
+                ga = torch.empty_like(im_a)
+                _call('arflow_census_bwd', _p(im_b), _p(im_a), _p(gham), None, _p(ga), B, H, W, ctx.r, _stream())
+            if ctx.needs_input_grad[1]:
+                gb = torch.empty_like(im_b)
+                _call('arflow_census_bwd', _p(im_a), _p(im_b), _p(gham), None, _p(gb), B, H, W, ctx.r, _stream())
+        return ga, gb, None
+
+
+# ------------------------------------------------------------------------------------------------
+class PhotoSumsFunction(torch.autograd.Function):
+    """[sum |im-recons|*mask, sum SSIMdist(recons*mask, im*mask), sum mask] in one launch
+    (losses/flow_loss.py:13-27).  Gradient w.r.t. recons only."""
+
+    @staticmethod
+    def forward(ctx, im, recons, mask):
+        _need_gpu(im, recons, mask)
+        im, recons = im.contiguous(), recons.contiguous()
+        mask = None if mask is None else mask.contiguous()
+        B, C, H, W = im.shape
+        sums = torch.empty(3, device=im.device, dtype=torch.float32)
+        with torch.cuda.device_of(im):
+            _call('arflow_photo_fwd', _p(im), _p(recons), _p(mask), None, _p(sums), B, C, H, W, _stream())
+        ctx.save_for_backward(im, recons, mask)
+        return sums
+
+    @staticmethod
+    def backward(ctx, gsums):
+        im, recons, mask = ctx.saved_tensors
+        B, C, H, W = im.shape
+        coef = gsums[:2].contiguous()
+        g = torch.empty_like(recons)
+        with torch.cuda.device_of(im):
+            _call('arflow_photo_bwd', _p(im), _p(recons), _p(mask), None, _p(coef), _p(g), B, C, H, W, _stream())
+        return None, g, None
+
+
+class SSIMFunction(torch.autograd.Function):
+    """SSIM(x, y, md=1) distance map of losses/loss_blocks.py:65-84."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        _need_gpu(x, y)
+        x, y = x.contiguous(), y.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, H - 2, W - 2, device=x.device, dtype=torch.float32)
+        sums = torch.empty(3, device=x.device, dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            # kernel convention: SSIM(recons*mask, im*mask) -> x plays "recons", y plays "im"
+            _call('arflow_photo_fwd', _p(y), _p(x), None, _p(out), _p(sums), B, C, H, W, _stream())
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, gmap):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gmap = gmap.contiguous()
+        coef = torch.zeros(2, device=x.device, dtype=torch.float32)
+        gx = gy = None
+        with torch.cuda.device_of(x):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                _call('arflow_photo_bwd', _p(y), _p(x), None, _p(gmap), _p(coef), _p(gx), B, C, H, W, _stream())
+            if ctx.needs_input_grad[1]:
+                gy = torch.empty_like(y)  # SSIM is symmetric in its arguments
+                _call('arflow_photo_bwd', _p(x), _p(y), None, _p(gmap), _p(coef), _p(gy), B, C, H, W, _stream())
+        return gx, gy
+
+
+# ------------------------------------------------------------------------------------------------
+class SmoothSumsFunction(torch.autograd.Function):
+    """[sum wx*pen(Dx flow), sum wy*pen(Dy flow)] (losses/loss_blocks.py:93-124,
+    losses/uflow_loss.py:62-102).  Gradient w.r.t. flow only (the image is detached / data)."""
+
+    @staticmethod
+    def forward(ctx, flow, img, flow_scale, alpha, order, wmode, penalty):
+        _need_gpu(flow, img)
+        flow, fbs = _flow_view(flow)
+        img = img.contiguous()
+        B, _, H, W = flow.shape
+        Ci = img.shape[1]
+        if img.shape[0] != B or img.shape[2:] != flow.shape[2:]:
+            raise ValueError('smoothness: image and flow must share batch and spatial size')
+        sums = torch.empty(2, device=flow.device, dtype=torch.float32)
+        args = (B, Ci, H, W, fbs, float(flow_scale), float(alpha), int(order), int(wmode), int(penalty))
+        with torch.cuda.device_of(flow):
+            _call('arflow_smooth_fwd', _p(flow), _p(img), _p(sums), *args, _stream())
+        ctx.save_for_backward(flow, img)
+        ctx.args = args
+        return sums
+
+    @staticmethod
+    def backward(ctx, gsums):
+        flow, img = ctx.saved_tensors
+        B, _, H, W = flow.shape
+        coef = gsums.contiguous()
+        g = torch.empty(B, 2, H, W, device=flow.device, dtype=torch.float32)
+        with torch.cuda.device_of(flow):
+            _call('arflow_smooth_bwd', _p(flow), _p(img), _p(coef), _p(g), *ctx.args, _stream())
+        return g, None, None, None, None, None, None
+
+
+def smooth_sums(flow, img, flow_scale, alpha, order, wmode, penalty):
+    return SmoothSumsFunction.apply(flow, img, flow_scale, alpha, order, wmode, penalty)
+
+
+# ------------------------------------------------------------------------------------------------
+def down4(img):
+    """downsample(img, is_flow=False, scale_factor=4) for H, W multiples of 4 (no gradient: the
+    reference only applies it to images, losses/uflow_loss.py:59-60)."""
+    _need_gpu(img)
+    img = img.detach().contiguous()
+    B, C, H, W = img.shape
+    out = torch.empty(B, C, H // 4, W // 4, device=img.device, dtype=torch.float32)
+    with torch.cuda.device_of(img):
+        _call('arflow_down4', _p(img), _p(out), B * C, H, W, _stream())
+    return out
+
+
+def up4_clamp_mul(small, valid=None):
+    """upsample(clamp(small,0,1), x4) * valid -- losses/uflow_loss.py:41-48, no gradient."""
+    _need_gpu(small, valid)
+    small = small.detach().contiguous()
+    B, one, h, w = small.shape
+    assert one == 1
+    valid = None if valid is None else valid.detach().contiguous()
+    out = torch.empty(B, 1, 4 * h, 4 * w, device=small.device, dtype=torch.float32)
+    with torch.cuda.device_of(small):
+        _call('arflow_up4_clamp_mul', _p(small), _p(valid), _p(out), B, h, w, _stream())
+    return out

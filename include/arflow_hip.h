@@ -1,0 +1,173 @@
+/*
+ * arflow_hip.h -- C ABI of libarflow_hip.so: the MI355X (gfx950) kernels for the ARFlow hot path
+ * (cost-volume correlation, bilinear warp, forward-splat occlusion maps, census / SSIM / L1
+ * photometric terms, edge-aware smoothness).
+ *
+ * Drop-in boundary.  The reference's only native boundary for this path is the pybind11 module
+ * `correlation_cuda` (models/correlation_package/correlation_cuda.cc:169-172) with
+ *     int forward (Tensor& input1, Tensor& input2, Tensor& rInput1, Tensor& rInput2, Tensor& output,
+ *                  int pad_size, int kernel_size, int max_displacement, int stride1, int stride2,
+ *                  int corr_type_multiply)                                  (correlation_cuda.cc:10-16)
+ *     int backward(input1, input2, rInput1, rInput2, gradOutput, gradInput1, gradInput2, ...6 ints)
+ *                                                                          (correlation_cuda.cc:89-96)
+ * arflow_corr_fwd / arflow_corr_bwd replace those two entry points.  Every other function below
+ * replaces a pure-PyTorch function of the reference (cited per function); the Python mirror in
+ * arflow_amd/ binds them with ctypes (see INTEGRATION.md for the reference-side stub).
+ *
+ * Conventions (all functions):
+ *   - plain pointers to DEVICE memory, fp32, NCHW, contiguous unless a stride argument says otherwise;
+ *   - outputs are caller-allocated; outputs that are accumulated into (scatter targets, reduction
+ *     sums) are zero-filled by the callee on the same stream (the reference's callee zero-fills too,
+ *     correlation_cuda.cc:40-42,112-115);
+ *   - `stream` is a hipStream_t (NULL = default stream); the call only enqueues work: no
+ *     synchronisation, no allocation, no global state -> re-entrant per stream, capturable in a
+ *     hipGraph;
+ *   - return 0 on success, ARFLOW_E* (< 0) for argument errors, -(int)hipError_t - 2000 when the
+ *     launch failed (the reference returns 0/1 and raises "CUDA call failed",
+ *     correlation_cuda.cc:81-83);  arflow_strerror() names a code.
+ */
+#ifndef ARFLOW_HIP_H
+#define ARFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* arflow_stream_t; /* hipStream_t */
+
+#define ARFLOW_OK 0
+#define ARFLOW_ENULL (-1001)   /* required pointer is NULL */
+#define ARFLOW_ESHAPE (-1002)  /* non-positive or inconsistent dimension */
+#define ARFLOW_EPARAM (-1003)  /* unsupported mode / parameter value */
+#define ARFLOW_ELAUNCH_BASE (-2000)
+
+#define ARFLOW_PAD_ZEROS 0
+#define ARFLOW_PAD_BORDER 1
+
+/* how flow is turned into grid_sample coordinates */
+#define ARFLOW_NORM_ARFLOW 0 /* utils/warp_utils.py:16-23,83-90: 2*(x+u)/(W-1)-1, un-normalised per align_corners */
+#define ARFLOW_NORM_UFLOW 1  /* utils/uflow_utils.py:53-77: 2*(x+u)/max(W-1,1)-1, align_corners=True */
+#define ARFLOW_NORM_UFLOW_ABS 2 /* same, but the "flow" argument already holds absolute coordinates
+                                   (resample(source, coords) with coords = flow_to_warp(flow)) */
+#define ARFLOW_COORDS_ABS 2     /* OR into `variant` / `mode` of splat_map / coord_mask: input holds
+                                   absolute coordinates instead of a flow */
+
+int arflow_abi_version(void);
+const char* arflow_strerror(int code);
+
+/* ---- cost volume ------------------------------------------------------------------------------
+ * out[b, i*(2d+1)+j, y, x] = (1/C) sum_c x1[b,c,y,x] * x2[b,c,y+i-d,x+j-d], zero outside.
+ * Replaces correlation_cuda.forward (correlation_cuda.cc:10-87), Correlation.forward
+ * (models/correlation_native.py:13-23) and compute_cost_volume (models/uflow_model.py:53-92).
+ * x1,x2: [B,C,H,W]; out: [B,(2d+1)^2,H,W]; 1 <= max_disp. */
+int arflow_corr_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W,
+                    int max_disp, arflow_stream_t stream);
+
+/* Gradients of the above (correlation_cuda.backward, correlation_cuda.cc:89-167; kernels
+ * correlation_cuda_kernel.cu:116-300).  gx1 / gx2 may be NULL to skip that gradient. */
+int arflow_corr_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2,
+                    int B, int C, int H, int W, int max_disp, arflow_stream_t stream);
+
+/* ---- bilinear warp ----------------------------------------------------------------------------
+ * out[b,c,y,x] = bilinear(src[b,c], x + flow[b,0,y,x], y + flow[b,1,y,x]) with torch grid_sample
+ * semantics (pad zeros|border, align_corners) after the reference's normalise/un-normalise round
+ * trip.  Replaces flow_warp (utils/warp_utils.py:83-90) and resample(flow_to_warp(.))
+ * (utils/uflow_utils.py:6-32,53-77).  src: [B,C,Hs,Ws]; flow: [B,2,H,W] with batch stride
+ * flow_bstride floats (>= 2*H*W; lets a [B,4,H,W] tensor be addressed as two flows without a copy);
+ * out: [B,C,H,W]; valid (nullable): [B,1,H,W] = mask_invalid(flow_to_warp(flow))
+ * (utils/uflow_utils.py:35-50). */
+int arflow_warp_fwd(const float* src, const float* flow, float* out, float* valid, int B, int C,
+                    int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode, int align_corners,
+                    int norm_mode, arflow_stream_t stream);
+
+/* gsrc (nullable, zero-filled here, 4-tap atomic scatter) and gflow (nullable, [B,2,H,W]
+ * contiguous). */
+int arflow_warp_bwd(const float* gout, const float* src, const float* flow, float* gsrc, float* gflow,
+                    int B, int C, int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode,
+                    int align_corners, int norm_mode, arflow_stream_t stream);
+
+/* ---- forward-splat maps -----------------------------------------------------------------------
+ * variant 0: compute_range_map (utils/uflow_utils.py:80-160, utils/warp_utils.py:158-239)
+ * variant 1: get_corresponding_map(grid+flow) (utils/warp_utils.py:26-80) -- clamped indices,
+ *            weight zeroed when a tap left the image.
+ * out [B,1,H,W] is zero-filled here. */
+int arflow_splat_map(const float* flow, float* out, int B, int H, int W, long flow_bstride,
+                     int variant, arflow_stream_t stream);
+
+/* mode 0: mask_invalid(flow_to_warp(flow)) closed interval (utils/uflow_utils.py:35-50)
+ * mode 1: border_mask(flow) open interval (utils/warp_utils.py:119-134) */
+int arflow_coord_mask(const float* flow, float* out, int B, int H, int W, long flow_bstride, int mode,
+                      arflow_stream_t stream);
+
+/* get_occu_mask_bidirection (utils/warp_utils.py:93-100): 1 where
+ * |f12 + warp(f21,f12)|^2 > scale*(|f12|^2+|warp(f21,f12)|^2) + bias. */
+int arflow_occ_bidir(const float* flow12, const float* flow21, float* out, int B, int H, int W,
+                     long bstride12, long bstride21, float scale, float bias, arflow_stream_t stream);
+
+/* ---- census / ternary ---------------------------------------------------------------------------
+ * Soft census distance between image_a and image_b (both [B,3,H,W], values in [0,1]):
+ * ham[b,0,y,x] = sum_k sq/(0.1+sq), sq = (t_a,k - t_b,k)^2, t = d/sqrt(0.81+d^2),
+ * d = 255*(gray(y+dy,x+dx) - gray(y,x)) over the (2r+1)^2 patch, zero padding
+ * (census_transform + soft_hamming, utils/uflow_utils.py:241-279; TernaryLoss,
+ * losses/loss_blocks.py:12-62).
+ * If mask != NULL the census_loss reduction (utils/uflow_utils.py:282-293) is fused:
+ *   sums[0] += sum (|ham|+0.01)^0.4 * pm,  sums[1] += sum pm,  pm = mask with an r-pixel zero border,
+ *   and dham[b,0,y,x] = pm * 0.4*(ham+0.01)^-0.6  (d loss-numerator / d ham) is written instead of ham
+ *   when dham != NULL.  sums (2 floats) is zero-filled here.  ham / dham may be NULL. */
+int arflow_census_fwd(const float* im_a, const float* im_b, const float* mask, float* ham, float* dham,
+                      float* sums, int B, int H, int W, int radius, arflow_stream_t stream);
+
+/* g_im_b[b,c,y,x] = scale[0] * d/d im_b ( sum_p gham[p] * ham[p] ); gham: [B,1,H,W];
+ * scale: device scalar (nullable = 1).  Gradient flows into image_b only (call with the images
+ * swapped for image_a: the distance is symmetric). */
+int arflow_census_bwd(const float* im_a, const float* im_b, const float* gham, const float* scale,
+                      float* g_im_b, int B, int H, int W, int radius, arflow_stream_t stream);
+
+/* ---- SSIM + L1 photometric term (losses/flow_loss.py:13-27, losses/loss_blocks.py:65-84) --------
+ * x = recons*mask, y = im*mask, 3x3 un-padded box SSIM, dist = clamp((1-SSIM)/2,0,1).
+ * sums[0] += sum |im-recons|*mask  (B*C*H*W terms)
+ * sums[1] += sum dist              (B*C*(H-2)*(W-2) terms)
+ * sums[2] += sum mask              (B*H*W terms)
+ * ssim_map (nullable): [B,C,H-2,W-2].  mask nullable (= ones).  sums zero-filled here. */
+int arflow_photo_fwd(const float* im, const float* recons, const float* mask, float* ssim_map,
+                     float* sums, int B, int C, int H, int W, arflow_stream_t stream);
+
+/* g_recons = coef[0] * d sums[0]/d recons + coef[1] * d sums[1]/d recons, or, when gmap != NULL,
+ * coef[0] * dL1 + sum_w gmap[w] * d dist[w] / d recons.  coef: 2 device floats. */
+int arflow_photo_bwd(const float* im, const float* recons, const float* mask, const float* gmap,
+                     const float* coef, float* g_recons, int B, int C, int H, int W,
+                     arflow_stream_t stream);
+
+/* ---- edge-aware smoothness ------------------------------------------------------------------------
+ * sums[0] += sum_{b,ch,y,x} wx * pen(Dx flow),  sums[1] += sum wy * pen(Dy flow)
+ * order 1: Dx f = f[x+1]-f[x];           wx = exp(-alpha * mean_c |img[x+1]-img[x]|)
+ * order 2: Dx f = f[x+2]-2f[x+1]+f[x];   wx from img[x+2]-img[x+1] (wmode 0, smooth_grad_2nd,
+ *          losses/loss_blocks.py:112-124) or img[x+2]-img[x] (wmode 1, UFlowLoss smooth_order 2,
+ *          losses/uflow_loss.py:81-102)
+ * penalty 0: |v| (loss_blocks.py:101-103), 1: sqrt(v^2 + 1e-6) (penalty_uflow :8-9, robust_l1(v^2)
+ * utils/uflow_utils.py:337-338).  flow: [B,2,H,W] (batch stride flow_bstride), flow values are
+ * multiplied by flow_scale first; img: [B,Ci,H,W].  sums (2 floats) zero-filled here. */
+int arflow_smooth_fwd(const float* flow, const float* img, float* sums, int B, int Ci, int H, int W,
+                      long flow_bstride, float flow_scale, float alpha, int order, int wmode, int penalty,
+                      arflow_stream_t stream);
+
+/* gflow ([B,2,H,W] contiguous) = coef[0]*d sums[0]/d flow + coef[1]*d sums[1]/d flow. */
+int arflow_smooth_bwd(const float* flow, const float* img, const float* coef, float* gflow, int B, int Ci,
+                      int H, int W, long flow_bstride, float flow_scale, float alpha, int order, int wmode,
+                      int penalty, arflow_stream_t stream);
+
+/* ---- resize helpers ---------------------------------------------------------------------------------
+ * downsample(img, x1/4) of utils/uflow_utils.py:185-204 for H,W multiples of 4 (= mean of the central
+ * 2x2 of each 4x4 block); in [B*C,H,W] -> out [B*C,H/4,W/4]. */
+int arflow_down4(const float* in, float* out, int planes, int H, int W, arflow_stream_t stream);
+
+/* out[b,0,y,x] = bilinear x4 upsample (align_corners=False, utils/uflow_utils.py:163-182) of
+ * clamp(in,0,1) times valid (nullable): the occlusion-mask assembly of losses/uflow_loss.py:41-48.
+ * in [B,1,h,w]; valid/out [B,1,4h,4w]. */
+int arflow_up4_clamp_mul(const float* in, const float* valid, float* out, int B, int h, int w,
+                         arflow_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARFLOW_HIP_H */

@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads and exports every symbol include/arflow_hip.h declares (no compute
+calls without a GPU), argument validation works, and the product ops refuse CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'arflow_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(arflow_[a-z0-9_]+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from arflow_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from arflow_amd import _lib
+    names = _declared()
+    assert len(names) >= 17
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), 'symbol %s missing from libarflow_hip.so' % n
+        if n not in ('arflow_strerror',):
+            assert n in _lib.PROTOTYPES, 'no ctypes prototype for %s' % n
+    assert set(_lib.PROTOTYPES) <= set(names)
+
+
+def test_prototype_arity_matches_header():
+    from arflow_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'arflow_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    for name, argtypes in _lib.PROTOTYPES.items():
+        m = re.search(r'\b%s\s*\(([^)]*)\)' % name, text)
+        assert m, name
+        params = [p for p in m.group(1).split(',') if p.strip() and p.strip() != 'void']
+        assert len(params) == len(argtypes), '%s: header has %d params, binding %d' % (name, len(params), len(argtypes))
+
+
+def test_argument_errors_without_gpu(lib):
+    # validation happens before any launch, so these are safe on a CPU-only host
+    assert lib.arflow_abi_version() == 1
+    assert lib.arflow_corr_fwd(None, None, None, 1, 1, 1, 1, 4, None) == -1001
+    one = ctypes.c_void_p(16)
+    assert lib.arflow_corr_fwd(one, one, one, 0, 1, 1, 1, 4, None) == -1002
+    assert lib.arflow_corr_fwd(one, one, one, 1, 1, 1, 1, 0, None) == -1003
+    assert lib.arflow_warp_fwd(one, one, one, None, 1, 1, 4, 4, 4, 4, 32, 7, 1, 0, None) == -1003
+    assert lib.arflow_warp_fwd(one, one, one, None, 1, 1, 4, 4, 4, 4, 3, 0, 1, 0, None) == -1002
+    assert lib.arflow_census_fwd(one, one, None, one, None, None, 1, 8, 8, 4, None) == -1003
+    assert lib.arflow_down4(one, one, 1, 6, 8, None) == -1002
+    assert b'NULL' in lib.arflow_strerror(-1001)
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    from arflow_amd import functional as AF, _lib
+    from arflow_amd.warp_utils import flow_warp
+    from arflow_amd.uflow_utils import census_loss
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(_lib.ArflowHipError):
+        AF.correlation(x, x, 4)
+    with pytest.raises(_lib.ArflowHipError):
+        flow_warp(x, torch.zeros(1, 2, 8, 8))
+    with pytest.raises(_lib.ArflowHipError):
+        census_loss(x, x, torch.ones(1, 1, 8, 8))
+
+
+def test_product_package_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under arflow_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'arflow_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, f)

@@ -1,0 +1,331 @@
+"""GPU parity: the gfx950 kernels (through the C ABI / autograd Functions) against
+ (1) the golden vectors frozen from the reference (tests/golden/*.npz) and
+ (2) the CPU oracle on seeded inputs at sizes the oracle finishes in seconds.
+
+Stated fp32 tolerances: correlation fwd/bwd atol 1e-6 (5e-6 with N(0,1) output
+gradients: 81 O(1) terms) rtol 1e-5; warp fwd atol (2e-6 + 4 ulp(coordinate)) * max|x|; warp bwd and
+splat maps (fp32 atomics, order-dependent) atol 1e-5 rtol 1e-4; scalar losses rtol 1e-5."""
+import pytest
+import torch
+
+from tests.conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def AF():
+    from arflow_amd import functional
+    return functional
+
+
+@pytest.fixture(scope='module')
+def oracle():
+    from oracle import ops
+    return ops
+
+
+def cu(t):
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_loaded_and_no_fallback():
+    from arflow_amd import _lib, functional
+    lib = _lib.load()
+    assert lib.arflow_abi_version() == 1
+    with pytest.raises(_lib.ArflowHipError):
+        functional.correlation(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4))  # CPU tensor must raise
+
+
+def test_correlation_golden(golden, AF):
+    g = golden('corr')
+    for name in g.names():
+        x1 = cu(g[name + '_x1']).requires_grad_(True)
+        x2 = cu(g[name + '_x2']).requires_grad_(True)
+        d = int(g[name + '_d'])
+        y = AF.correlation(x1, x2, d)
+        assert_close(y, g[name + '_y'], 1e-6, 1e-5, name + ' fwd')
+        gx1, gx2 = torch.autograd.grad(y, [x1, x2], cu(g[name + '_g']))
+        assert_close(gx1, g[name + '_gx1'], 5e-6, 1e-5, name + ' gx1')
+        assert_close(gx2, g[name + '_gx2'], 5e-6, 1e-5, name + ' gx2')
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 24, 40, 4), (1, 192, 6, 10, 4), (2, 96, 12, 20, 4), (1, 7, 33, 65, 4),
+                                   (1, 64, 48, 80, 4), (3, 5, 17, 31, 2), (1, 3, 9, 9, 6), (2, 16, 96, 160, 4)])
+def test_correlation_vs_oracle(AF, oracle, shape):
+    B, C, H, W, d = shape
+    gen = torch.Generator().manual_seed(B * 1000 + C)
+    x1 = torch.randn(B, C, H, W, generator=gen)
+    x2 = torch.randn(B, C, H, W, generator=gen)
+    go = torch.randn(B, (2 * d + 1) ** 2, H, W, generator=gen)
+    ref = oracle.correlation(x1, x2, d)
+    r1, r2 = oracle.correlation_backward(go, x1, x2, d)
+    a = cu(x1).requires_grad_(True)
+    b = cu(x2).requires_grad_(True)
+    y = AF.correlation(a, b, d)
+    assert_close(y, ref, 1e-6, 1e-5, 'corr fwd %s' % (shape,))
+    g1, g2 = torch.autograd.grad(y, [a, b], cu(go))
+    assert_close(g1, r1, 5e-6, 1e-5, 'corr gx1 %s' % (shape,))
+    assert_close(g2, r2, 5e-6, 1e-5, 'corr gx2 %s' % (shape,))
+    # only one gradient requested
+    a2 = cu(x1).requires_grad_(True)
+    y2 = AF.correlation(a2, cu(x2), d)
+    g1b, = torch.autograd.grad(y2, [a2], cu(go))
+    assert_close(g1b, r1, 5e-6, 1e-5, 'corr gx1-only')
+
+
+def test_correlation_module_signature(AF):
+    from arflow_amd.correlation import Correlation, compute_cost_volume
+    m = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
+    x = torch.randn(1, 8, 12, 20, device='cuda')
+    assert m(x, x).shape == (1, 81, 12, 20)
+    with pytest.raises(NotImplementedError):
+        Correlation(pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2)
+    with pytest.raises(ValueError):
+        compute_cost_volume(x[:, :, :4], x[:, :, :4], 4)
+
+
+def _warp_tol(x, H, W):
+    ulp = 2.0 ** -23 * max(H, W)
+    return (2e-6 + 4 * ulp) * float(x.abs().max())
+
+
+def test_flow_warp_golden(golden):
+    from arflow_amd.warp_utils import flow_warp
+    g = golden('warp')
+    for name in g.names():
+        for pad in ('zeros', 'border'):
+            for ac in (True, False):
+                x = cu(g[name + '_x']).requires_grad_(True)
+                fl = cu(g[name + '_flow']).requires_grad_(True)
+                tag = '%s_%s_%d' % (name, pad, int(ac))
+                y = flow_warp(x, fl, pad=pad, align_corners=ac)
+                assert_close(y, g[tag + '_y'], _warp_tol(x.detach(), *x.shape[2:]), 1e-5, tag + ' fwd')
+                gx, gf = torch.autograd.grad(y, [x, fl], cu(g[name + '_g']))
+                assert_close(gx, g[tag + '_gx'], 1e-5, 1e-4, tag + ' gx')
+                if name != 'integer':  # at exactly-integer coordinates d/dflow is one-sided; see next test
+                    assert_close(gf, g[tag + '_gf'], 3e-5, 1e-4, tag + ' gflow')
+
+
+def test_resample_family_golden(golden):
+    from arflow_amd import uflow_utils as U, uflow_resampler as R
+    g = golden('warp')
+    for name in g.names():
+        x = cu(g[name + '_x']).requires_grad_(True)
+        fl = cu(g[name + '_flow']).requires_grad_(True)
+        coords = U.flow_to_warp(fl)
+        assert_close(coords, g[name + '_coords'], 0, 0, name + ' flow_to_warp')
+        assert_close(U.mask_invalid(coords), g[name + '_mask_invalid'], 0, 0, name + ' mask_invalid')
+        assert_close(U.mask_invalid_flow(fl), g[name + '_mask_invalid'], 0, 0, name + ' mask_invalid_flow')
+        tol = _warp_tol(x.detach(), *x.shape[2:])
+        y = U.resample(x, coords)
+        assert_close(y, g[name + '_resample_y'], tol, 1e-5, name + ' resample')
+        gx, gf = torch.autograd.grad(y, [x, fl], cu(g[name + '_g']))
+        assert_close(gx, g[name + '_resample_gx'], 1e-5, 1e-4, name + ' resample gx')
+        if name != 'integer':
+            assert_close(gf, g[name + '_resample_gf'], 3e-5, 1e-4, name + ' resample gflow')
+        y2 = U.resample_flow(x, fl)
+        assert_close(y2, g[name + '_resample_y'], tol, 1e-5, name + ' resample_flow')
+        nhwc = R.resampler(x.detach().permute(0, 2, 3, 1).contiguous(), coords.detach().permute(0, 2, 3, 1).contiguous())
+        assert_close(nhwc, g[name + '_resampler_nhwc'], tol + 2e-6, 1e-5, name + ' resampler nhwc')
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 48, 80, 'zeros', True), (1, 64, 24, 40, 'border', True),
+                                 (2, 3, 96, 160, 'border', False), (1, 16, 31, 57, 'zeros', False)])
+def test_flow_warp_vs_oracle(AF, oracle, cfg):
+    B, C, H, W, pad, ac = cfg
+    gen = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, C, H, W, generator=gen)
+    fl = 3.0 * torch.randn(B, 2, H, W, generator=gen)
+    go = torch.randn(B, C, H, W, generator=gen)
+    xr, fr = x.clone().requires_grad_(True), fl.clone().requires_grad_(True)
+    ref = oracle.flow_warp(xr, fr, pad=pad, align_corners=ac)
+    rgx, rgf = torch.autograd.grad(ref, [xr, fr], go)
+    a, f = cu(x).requires_grad_(True), cu(fl).requires_grad_(True)
+    y = AF.warp(a, f, pad=pad, align_corners=ac)
+    assert_close(y, ref, _warp_tol(x, H, W), 1e-5, 'warp fwd')
+    gx, gf = torch.autograd.grad(y, [a, f], cu(go))
+    assert_close(gx, rgx, 2e-5, 1e-4, 'warp gx')
+    # d/dflow multiplies sums over C channels by up to W/2: scale the absolute tolerance with it
+    assert_close(gf, rgf, 1e-5 * (C ** 0.5) * float(x.abs().max()) * 4, 2e-4, 'warp gflow')
+
+
+def test_warp_strided_flow_and_flow_only_grad(AF, oracle):
+    """A [B,4,H,W] (fw,bw) tensor is consumed in place through the batch stride, and a detached
+    source yields only d/dflow (the loss-side call, losses/uflow_loss.py:31)."""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 20, 28, generator=gen)
+    f4 = 2 * torch.randn(2, 4, 20, 28, generator=gen)
+    for sl in (slice(0, 2), slice(2, 4)):
+        fr = f4[:, sl].clone().requires_grad_(True)
+        ref = oracle.resample(x, oracle.flow_to_warp(fr))
+        rg, = torch.autograd.grad(ref, [fr], torch.ones_like(ref))
+        f4c = cu(f4).requires_grad_(True)
+        y = AF.warp(cu(x), f4c[:, sl], pad='zeros', align_corners=True, norm=AF.NORM_UFLOW)
+        assert_close(y, ref, 1e-5, 1e-5, 'strided warp')
+        g, = torch.autograd.grad(y, [f4c], torch.ones_like(y))
+        assert_close(g[:, sl], rg, 1e-4, 2e-4, 'strided gflow')
+        other = slice(2, 4) if sl.start == 0 else slice(0, 2)
+        assert float(g[:, other].abs().max()) == 0.0
+
+
+def test_masks_golden(golden):
+    from arflow_amd import warp_utils as WU, uflow_utils as U
+    g = golden('masks')
+    for name in g.names():
+        fl = cu(g[name + '_flow'])
+        assert_close(U.compute_range_map(fl), g[name + '_range_map'], 1e-5, 1e-4, name + ' range map')
+        assert_close(WU.compute_range_map(fl), g[name + '_range_map_wu'], 1e-5, 1e-4, name + ' range map wu')
+        coords = U.flow_to_warp(fl)
+        assert_close(WU.get_corresponding_map(coords), g[name + '_corr_map'], 1e-5, 1e-4, name + ' corr map')
+        assert_close(WU.get_occu_mask_backward(fl, th=0.0), g[name + '_occ_back_0'], 1e-5, 1e-4, name + ' occ soft')
+        # thresholded masks: compare where the reference's soft value is not within 1e-5 of the threshold
+        soft = 1.0 - g[name + '_occ_back_0']
+        safe = (soft - 0.2).abs() > 1e-5
+        got = WU.get_occu_mask_backward(fl, th=0.2).cpu()
+        assert torch.equal(got[safe], g[name + '_occ_back_02'][safe]), name + ' occ back'
+        assert_close(WU.border_mask(fl), g[name + '_border_mask'], 0, 0, name + ' border mask')
+        for key, other in (('_occ_bidir', -0.7 * fl.flip(-1)), ('_occ_bidir_neg', -fl)):
+            got = WU.get_occu_mask_bidirection(fl, other.contiguous()).cpu()
+            ref = g[name + key]
+            assert float((got != ref).float().mean()) <= 0.01, name + key  # threshold ties may flip a pixel
+
+
+def test_photo_blocks_golden(golden):
+    from arflow_amd import loss_blocks as LB, uflow_utils as U
+    g = golden('photo')
+    for name in g.names():
+        im1, im2, fl, mask = (cu(g[name + k]) for k in ('_im1', '_im2', '_flow', '_mask'))
+        a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
+        y = LB.SSIM(a, b)
+        assert_close(y, g[name + '_ssim'], 5e-6, 1e-5, name + ' ssim')
+        ga, gb = torch.autograd.grad(y, [a, b], cu(g[name + '_ssim_g']))
+        assert_close(ga, g[name + '_ssim_ga'], 5e-5, 2e-4, name + ' ssim ga')
+        assert_close(gb, g[name + '_ssim_gb'], 5e-5, 2e-4, name + ' ssim gb')
+        for md, sd in ((1, False), (3, True)):
+            tag = '%s_ternary_%d_%d' % (name, md, int(sd))
+            a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
+            dist, tm = LB.TernaryLoss(a, b, md, sd)
+            assert_close(dist, g[tag + '_dist'], 2e-5, 2e-5, tag)
+            assert_close(tm, g[tag + '_mask'], 0, 0, tag + ' mask')
+            ga, gb = torch.autograd.grad(dist, [a, b], cu(g[tag + '_g']))
+            assert_close(ga, g[tag + '_ga'], 2e-3, 2e-4, tag + ' ga')
+            assert_close(gb, g[tag + '_gb'], 2e-3, 2e-4, tag + ' gb')
+        for ps in (7, 3):
+            b = im2.clone().requires_grad_(True)
+            y = U.census_loss(im1, b, mask, ps)
+            assert_close(y, g['%s_census_%d' % (name, ps)], 1e-6, 1e-5, name + ' census')
+            gb, = torch.autograd.grad(y, [b])
+            ref = g['%s_census_%d_gb' % (name, ps)]
+            assert_close(gb, ref, 1e-6 + 1e-4 * float(ref.abs().max()), 1e-4, name + ' census gb')
+        for fn, key in ((lambda f: LB.smooth_grad_1st(f, im1, 10.), 'sm1_abs'),
+                        (lambda f: LB.smooth_grad_1st(f, im1, 10., penalty='uflow'), 'sm1_uflow'),
+                        (lambda f: LB.smooth_grad_2nd(f, im1, 10.), 'sm2')):
+            f = fl.clone().requires_grad_(True)
+            y = fn(f)
+            assert_close(y, g['%s_%s' % (name, key)], 1e-7, 1e-5, name + ' ' + key)
+            gf, = torch.autograd.grad(y, [f])
+            ref = g['%s_%s_gf' % (name, key)]
+            assert_close(gf, ref, 1e-8 + 1e-5 * float(ref.abs().max()), 1e-4, name + ' ' + key + ' grad')
+
+
+def test_resize_helpers_golden(golden, AF):
+    g = golden('aux')
+    assert_close(AF.down4(cu(g['img'])), g['down4'], 1e-6, 1e-5, 'down4')
+    up = AF.up4_clamp_mul(cu(g['m']))
+    assert_close(up, g['up4'], 1e-6, 1e-5, 'up4 (inputs already in [0,1])')
+
+
+def _loss_cases():
+    from tests.test_oracle_golden import _loss_cases as lc
+    return lc()
+
+
+@pytest.mark.parametrize('group', [0, 1, 2])
+def test_loss_modules_golden(golden, group):
+    from arflow_amd import losses as L
+    from arflow_amd.config import AttrDict
+    g = golden('losses')
+    cases = _loss_cases()[group]
+    cls = (L.UFlowLoss, L.unFlowLoss, L.FullResLoss)[group]
+    img = cu(g['img'])
+    for name, cfg in cases:
+        flows = [cu(g['flow%d' % i]).requires_grad_(True) for i in range(5)]
+        res = cls(AttrDict(cfg))(flows, img)
+        assert_close(res[0], g[name + '_total'], 1e-6, 5e-5, name + ' total')
+        assert_close(res[1], g[name + '_warp'], 1e-6, 5e-5, name + ' warp')
+        assert_close(res[2], g[name + '_smooth'], 1e-6, 5e-5, name + ' smooth')
+        assert_close(res[3], g[name + '_absflow'], 1e-6, 1e-5, name + ' |flow|')
+        if len(res) > 4:
+            assert_close(res[4], g[name + '_mask1'], 1e-5, 1e-4, name + ' mask1')
+        grads = torch.autograd.grad(res[0], flows, allow_unused=True)
+        for i, gi in enumerate(grads):
+            ref = g['%s_g%d' % (name, i)]
+            gi = gi if gi is not None else torch.zeros_like(ref).cuda()
+            assert_close(gi, ref, 2e-7 + 2e-4 * float(ref.abs().max()), 2e-3, '%s dflow%d' % (name, i))
+
+
+def test_census_vs_oracle_midsize(oracle):
+    from arflow_amd import uflow_utils as U
+    gen = torch.Generator().manual_seed(11)
+    B, H, W = 2, 96, 160
+    im1 = torch.rand(B, 3, H, W, generator=gen)
+    im2 = (im1 + 0.1 * torch.randn(B, 3, H, W, generator=gen)).clamp(0, 1)
+    mask = (torch.rand(B, 1, H, W, generator=gen) > 0.2).float()
+    b = im2.clone().requires_grad_(True)
+    ref = oracle.census_loss(im1, b, mask)
+    rg, = torch.autograd.grad(ref, [b])
+    bc = cu(im2).requires_grad_(True)
+    y = U.census_loss(cu(im1), bc, cu(mask))
+    assert_close(y, ref, 1e-6, 1e-5, 'census loss')
+    gb, = torch.autograd.grad(y, [bc])
+    assert_close(gb, rg, 1e-4 * float(rg.abs().max()), 1e-4, 'census grad')
+
+
+def test_full_size_properties(AF):
+    """BASELINE config-2 sizes (B=8, 96x160 C=32 and 384x640 images): size-independent properties."""
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    x1 = torch.randn(8, 32, 96, 160, device='cuda', generator=gen)
+    x2 = torch.randn(8, 32, 96, 160, device='cuda', generator=gen)
+    y = AF.correlation(x1, x2, 4)
+    # centre channel is the per-pixel mean product
+    assert_close(y[:, 40], (x1 * x2).mean(1), 1e-6, 1e-5, 'centre channel')
+    # shifting x2 by one pixel moves the volume one displacement channel
+    x2s = torch.roll(x2, shifts=1, dims=3)
+    ys = AF.correlation(x1, x2s, 4)
+    assert_close(ys[:, 41, :, 8:-8], y[:, 40, :, 8:-8], 1e-6, 1e-5, 'shift equivariance')
+    # linearity in x1
+    y2 = AF.correlation(2.5 * x1, x2, 4)
+    assert_close(y2, 2.5 * y, 1e-6, 1e-5, 'linearity')
+    # <corr(x1,x2), g> == <x1, gx1> == <x2, gx2>  (adjoint identity)
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    go = torch.randn(8, 81, 96, 160, device='cuda', generator=gen)
+    out = AF.correlation(a, b, 4)
+    g1, g2 = torch.autograd.grad(out, [a, b], go)
+    lhs = float((out.double() * go.double()).sum())
+    assert abs(float((g1.double() * x1.double()).sum()) - lhs) <= 1e-4 * abs(lhs) + 1e-2
+    assert abs(float((g2.double() * x2.double()).sum()) - lhs) <= 1e-4 * abs(lhs) + 1e-2
+    # warp with zero flow is the identity (align_corners=True), full-resolution 3-channel image
+    img = torch.rand(8, 3, 384, 640, device='cuda', generator=gen)
+    z = torch.zeros(8, 2, 384, 640, device='cuda')
+    assert_close(AF.warp(img, z, 'zeros', True, AF.NORM_UFLOW), img, 4e-5, 0, 'identity warp')
+    # census(a, a) = 0.01^0.4 on the valid interior
+    from arflow_amd import uflow_utils as U
+    ones = torch.ones(8, 1, 384, 640, device='cuda')
+    assert abs(float(U.census_loss(img, img, ones)) - 0.01 ** 0.4) < 1e-5
+    # range map of zero flow is all ones
+    assert_close(AF.splat_map(z, 0), ones, 0, 0, 'range map identity')
+
+
+def test_determinism_of_atomic_free_kernels(AF):
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    x1 = torch.randn(2, 32, 48, 80, device='cuda', generator=gen, requires_grad=True)
+    x2 = torch.randn(2, 32, 48, 80, device='cuda', generator=gen, requires_grad=True)
+    go = torch.randn(2, 81, 48, 80, device='cuda', generator=gen)
+    outs = []
+    for _ in range(2):
+        y = AF.correlation(x1, x2, 4)
+        outs.append((y.detach().clone(),) + tuple(t.clone() for t in torch.autograd.grad(y, [x1, x2], go)))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
