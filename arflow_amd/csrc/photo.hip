@@ -160,19 +160,21 @@ __device__ __forceinline__ Win window_stats(const float (*tx)[PITCH], const floa
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float a = tx[r + i][c + j], b = ty[r + i][c + j];
+      // the reference pools the already-rounded products x*x, y*y, x*y (AvgPool2d of a product
+      // tensor, loss_blocks.py:76-78): round each product, add in row-major order, divide by 9.
+      // sigma = E[x^2]-mu^2 cancels catastrophically, so the operation order is kept.
       sxv += a;
       syv += b;
-      sxx = fmaf(a, a, sxx);
-      syy = fmaf(b, b, syy);
-      sxyv = fmaf(a, b, sxyv);
+      sxx += a * a;
+      syy += b * b;
+      sxyv += a * b;
     }
   Win w;
-  const float k = 1.f / 9.f;
-  w.mx = sxv * k;
-  w.my = syv * k;
-  w.sx = sxx * k - w.mx * w.mx;
-  w.sy = syy * k - w.my * w.my;
-  w.sxy = sxyv * k - w.mx * w.my;
+  w.mx = sxv / 9.f;
+  w.my = syv / 9.f;
+  w.sx = sxx / 9.f - w.mx * w.mx;
+  w.sy = syy / 9.f - w.my * w.my;
+  w.sxy = sxyv / 9.f - w.mx * w.my;
   return w;
 }
 
