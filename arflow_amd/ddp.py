@@ -1,0 +1,104 @@
+"""One-process-per-GPU data parallelism for the image-pair batch (RCCL over xGMI).
+
+The reference only has single-process ``torch.nn.DataParallel`` (trainer/base_trainer.py:75): per
+step it broadcasts the parameters, scatters the batch, gathers the flows to GPU 0 and reduce-adds
+the gradients.  Here every rank owns a full replica and its shard of the pairs; the only
+communication is the gradient all-reduce:
+
+  * all gradients live in ONE flat fp32 buffer (9-29 MB for these models);
+    ``param.grad`` are views into it, so there is no flatten/unflatten copy;
+  * the buffer is cut into a few contiguous buckets in reverse registration order (the order
+    backward produces gradients); a bucket's all-reduce is launched asynchronously from the
+    post-accumulate-grad hook of its last parameter, overlapping the rest of backward;
+  * on the 8-GPU xGMI mesh RCCL serves this size class with a direct reduce-scatter/all-gather
+    (7 links in parallel), so few large buckets beat many small ones: per-link-bound, ~0.1 ms.
+
+Works with ``backend='nccl'`` (= RCCL on ROCm) and with ``gloo`` on CPU (tests, world_size 2).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReduce:
+    def __init__(self, module, n_buckets=4, process_group=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        assert params, 'no trainable parameters'
+        dev, dt = params[0].device, params[0].dtype
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        # reverse registration order ~ the order in which backward finishes gradients
+        order = list(reversed(params))
+        off = 0
+        self._spans = []
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._spans.append((p, off, n))
+            off += n
+        # contiguous buckets of ~equal size
+        n_buckets = max(1, min(n_buckets, len(order)))
+        target = (total + n_buckets - 1) // n_buckets
+        self.buckets = []  # (start, end, [params])
+        start, cur, members = 0, 0, []
+        for p, o, n in self._spans:
+            members.append(p)
+            cur = o + n
+            if cur - start >= target and len(self.buckets) < n_buckets - 1:
+                self.buckets.append((start, cur, members))
+                start, members = cur, []
+        if members:
+            self.buckets.append((start, cur, members))
+        self._pending = [0] * len(self.buckets)
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for bi, (_, _, members) in enumerate(self.buckets):
+                for p in members:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self._use_avg = self.world > 1 and dist.get_backend(process_group) == 'nccl'
+        self.reset()
+
+    def _make_hook(self, bi):
+        def hook(param):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                s, e, _ = self.buckets[bi]
+                op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+                self._handles.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
+        return hook
+
+    def reset(self):
+        self._pending = [len(m) for _, _, m in self.buckets]
+        self._handles = []
+
+    def zero_grad(self):
+        """One memset instead of one per parameter; keeps ``param.grad`` aliased to the flat buffer."""
+        self.flat.zero_()
+        for p, o, n in self._spans:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + o * self.flat.element_size():
+                p.grad = self.flat[o:o + n].view_as(p)
+        self.reset()
+
+    def finish(self):
+        """Wait for the bucket all-reduces launched during backward (and launch any whose parameters
+        received no gradient this step), leaving the averaged gradient in ``param.grad``."""
+        if self.world == 1:
+            return
+        for bi, (s, e, _) in enumerate(self.buckets):
+            if self._pending[bi] != 0:  # some parameter got no gradient: reduce the bucket now
+                op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+                self._handles.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
+        for h in self._handles:
+            h.wait()
+        if not self._use_avg:
+            self.flat.div_(self.world)
+        self.reset()
+
+    def broadcast_parameters(self, src=0):
+        if self.world == 1:
+            return
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            dist.broadcast(t.data, src=src, group=self.group)

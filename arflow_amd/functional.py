@@ -42,9 +42,38 @@ def _flow_view(flow):
     return flow, 2 * H * W
 
 
-def _call(name, *args):
+_timing = None  # list of (name, key, start_event, end_event) while kernel timing is on
+
+
+def start_kernel_timing():
+    """Bracket every C-ABI launch with HIP events recorded on the launch stream (torch's current
+    stream).  Used by bench.py for the per-kernel roofline; off by default."""
+    global _timing
+    _timing = []
+
+
+def stop_kernel_timing():
+    """-> {(name, shape_key): [ms, ...]} ; synchronises."""
+    global _timing
+    rec, _timing = _timing or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for name, key, e0, e1 in rec:
+        out.setdefault((name, key), []).append(e0.elapsed_time(e1))
+    return out
+
+
+def _call(name, *args, key=None):
     lib = _lib.load()
-    _lib.check(getattr(lib, name)(*args), name)
+    if _timing is not None and key is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        _timing.append((name, key, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
+    _lib.check(rc, name)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -63,7 +92,7 @@ class CorrelationFunction(torch.autograd.Function):
         d = int(max_displacement)
         out = torch.empty(B, (2 * d + 1) ** 2, H, W, device=x1.device, dtype=torch.float32)
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, W, d, _stream())
+            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, W, d, _stream(), key=(B, C, H, W, d))
         ctx.save_for_backward(x1, x2)
         ctx.d = d
         return out
@@ -76,7 +105,8 @@ class CorrelationFunction(torch.autograd.Function):
         g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_bwd', _p(gout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, W, ctx.d, _stream())
+            _call('arflow_corr_bwd', _p(gout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, W, ctx.d, _stream(),
+                  key=(B, C, H, W, ctx.d))
         return g1, g2, None
 
 
@@ -98,7 +128,7 @@ class WarpFunction(torch.autograd.Function):
         out = torch.empty(B, C, H, W, device=src.device, dtype=torch.float32)
         with torch.cuda.device_of(src):
             _call('arflow_warp_fwd', _p(src), _p(flow), _p(out), None, B, C, Hs, Ws, H, W, fbs, pad,
-                  int(bool(align_corners)), norm, _stream())
+                  int(bool(align_corners)), norm, _stream(), key=(B, C, H, W))
         ctx.save_for_backward(src, flow)
         ctx.cfg = (pad, int(bool(align_corners)), norm, fbs)
         return out
@@ -114,7 +144,7 @@ class WarpFunction(torch.autograd.Function):
         gflow = torch.empty(B, 2, H, W, device=src.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         with torch.cuda.device_of(src):
             _call('arflow_warp_bwd', _p(gout), _p(src), _p(flow), _p(gsrc), _p(gflow), B, C, Hs, Ws, H, W, fbs,
-                  pad, ac, norm, _stream())
+                  pad, ac, norm, _stream(), key=(B, C, H, W, gsrc is not None))
         return gsrc, gflow, None, None, None
 
 
@@ -128,7 +158,7 @@ def _flow_map(name, flow, *extra):
     B, _, H, W = flow.shape
     out = torch.empty(B, 1, H, W, device=flow.device, dtype=torch.float32)
     with torch.cuda.device_of(flow):
-        _call(name, _p(flow), _p(out), B, H, W, fbs, *extra, _stream())
+        _call(name, _p(flow), _p(out), B, H, W, fbs, *extra, _stream(), key=(B, H, W))
     return out
 
 
@@ -150,7 +180,8 @@ def occ_bidir(flow12, flow21, scale=0.01, bias=0.5):
     B, _, H, W = f12.shape
     out = torch.empty(B, 1, H, W, device=f12.device, dtype=torch.float32)
     with torch.cuda.device_of(f12):
-        _call('arflow_occ_bidir', _p(f12), _p(f21), _p(out), B, H, W, s12, s21, float(scale), float(bias), _stream())
+        _call('arflow_occ_bidir', _p(f12), _p(f21), _p(out), B, H, W, s12, s21, float(scale), float(bias), _stream(),
+              key=(B, H, W))
     return out
 
 
@@ -171,11 +202,12 @@ class CensusLossFunction(torch.autograd.Function):
         sums = torch.empty(2, device=im_a.device, dtype=torch.float32)
         dham = torch.empty(B, 1, H, W, device=im_a.device, dtype=torch.float32)
         with torch.cuda.device_of(im_a):
-            _call('arflow_census_fwd', _p(im_a), _p(im_b), _p(mask), None, _p(dham), _p(sums), B, H, W, r, _stream())
+            _call('arflow_census_fwd', _p(im_a), _p(im_b), _p(mask), None, _p(dham), _p(sums), B, H, W, r, _stream(),
+                  key=(B, H, W))
         inv = 1.0 / (sums[1] + 1e-6)
         ctx.save_for_backward(im_a, im_b, dham, inv)
         ctx.r = r
-        return sums[0] * inv
+        return sums[0] / (sums[1] + 1e-6)
 
     @staticmethod
     def backward(ctx, gloss):
@@ -186,10 +218,12 @@ class CensusLossFunction(torch.autograd.Function):
         with torch.cuda.device_of(im_a):
             if ctx.needs_input_grad[1]:
                 gb = torch.empty_like(im_b)
-                _call('arflow_census_bwd', _p(im_a), _p(im_b), _p(dham), _p(scale), _p(gb), B, H, W, ctx.r, _stream())
+                _call('arflow_census_bwd', _p(im_a), _p(im_b), _p(dham), _p(scale), _p(gb), B, H, W, ctx.r, _stream(),
+                      key=(B, H, W))
             if ctx.needs_input_grad[0]:
                 ga = torch.empty_like(im_a)  # the distance is symmetric in (a, b)
-                _call('arflow_census_bwd', _p(im_b), _p(im_a), _p(dham), _p(scale), _p(ga), B, H, W, ctx.r, _stream())
+                _call('arflow_census_bwd', _p(im_b), _p(im_a), _p(dham), _p(scale), _p(ga), B, H, W, ctx.r, _stream(),
+                      key=(B, H, W))
         return ga, gb, None, None
 
 
@@ -240,7 +274,8 @@ class PhotoSumsFunction(torch.autograd.Function):
         B, C, H, W = im.shape
         sums = torch.empty(3, device=im.device, dtype=torch.float32)
         with torch.cuda.device_of(im):
-            _call('arflow_photo_fwd', _p(im), _p(recons), _p(mask), None, _p(sums), B, C, H, W, _stream())
+            _call('arflow_photo_fwd', _p(im), _p(recons), _p(mask), None, _p(sums), B, C, H, W, _stream(),
+                  key=(B, C, H, W))
         ctx.save_for_backward(im, recons, mask)
         return sums
 
@@ -251,7 +286,8 @@ class PhotoSumsFunction(torch.autograd.Function):
         coef = gsums[:2].contiguous()
         g = torch.empty_like(recons)
         with torch.cuda.device_of(im):
-            _call('arflow_photo_bwd', _p(im), _p(recons), _p(mask), None, _p(coef), _p(g), B, C, H, W, _stream())
+            _call('arflow_photo_bwd', _p(im), _p(recons), _p(mask), None, _p(coef), _p(g), B, C, H, W, _stream(),
+                  key=(B, C, H, W))
         return None, g, None
 
 
@@ -305,7 +341,7 @@ class SmoothSumsFunction(torch.autograd.Function):
         sums = torch.empty(2, device=flow.device, dtype=torch.float32)
         args = (B, Ci, H, W, fbs, float(flow_scale), float(alpha), int(order), int(wmode), int(penalty))
         with torch.cuda.device_of(flow):
-            _call('arflow_smooth_fwd', _p(flow), _p(img), _p(sums), *args, _stream())
+            _call('arflow_smooth_fwd', _p(flow), _p(img), _p(sums), *args, _stream(), key=(B, Ci, H, W))
         ctx.save_for_backward(flow, img)
         ctx.args = args
         return sums
@@ -317,7 +353,8 @@ class SmoothSumsFunction(torch.autograd.Function):
         coef = gsums.contiguous()
         g = torch.empty(B, 2, H, W, device=flow.device, dtype=torch.float32)
         with torch.cuda.device_of(flow):
-            _call('arflow_smooth_bwd', _p(flow), _p(img), _p(coef), _p(g), *ctx.args, _stream())
+            _call('arflow_smooth_bwd', _p(flow), _p(img), _p(coef), _p(g), *ctx.args, _stream(),
+                  key=(B, img.shape[1], H, W))
         return g, None, None, None, None, None, None
 
 
@@ -334,7 +371,7 @@ def down4(img):
     B, C, H, W = img.shape
     out = torch.empty(B, C, H // 4, W // 4, device=img.device, dtype=torch.float32)
     with torch.cuda.device_of(img):
-        _call('arflow_down4', _p(img), _p(out), B * C, H, W, _stream())
+        _call('arflow_down4', _p(img), _p(out), B * C, H, W, _stream(), key=(B * C, H, W))
     return out
 
 
@@ -347,5 +384,5 @@ def up4_clamp_mul(small, valid=None):
     valid = None if valid is None else valid.detach().contiguous()
     out = torch.empty(B, 1, 4 * h, 4 * w, device=small.device, dtype=torch.float32)
     with torch.cuda.device_of(small):
-        _call('arflow_up4_clamp_mul', _p(small), _p(valid), _p(out), B, h, w, _stream())
+        _call('arflow_up4_clamp_mul', _p(small), _p(valid), _p(out), B, h, w, _stream(), key=(B, h, w))
     return out

@@ -1,0 +1,126 @@
+"""PWCLite host model (ARFlow) on the gfx950 ops.  Same constructor cfg keys, forward contract and
+state_dict layout as models/pwclite.py:109-283; correlation and warp are the HIP autograd ops."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..correlation import Correlation
+from ..warp_utils import flow_warp
+from .blocks import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, FlowEstimatorReduce, conv,
+                     init_conv_weights, pair_batches)
+
+
+class PWCLite(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.search_range = 4
+        self.num_chs = [3, 16, 32, 64, 96, 128, 192]
+        self.output_level = 4
+        self.num_levels = 7
+        self.leakyRELU = nn.LeakyReLU(0.1, inplace=True)
+        self.feature_pyramid_extractor = FeatureExtractor(self.num_chs)
+        self.upsample = cfg.upsample
+        self.n_frames = cfg.n_frames
+        self.reduce_dense = cfg.reduce_dense
+        self.corr = Correlation(pad_size=self.search_range, kernel_size=1, max_displacement=self.search_range,
+                                stride1=1, stride2=1, corr_multiply=1)
+        self.dim_corr = (self.search_range * 2 + 1) ** 2
+        self.num_ch_in = 32 + (self.dim_corr + 2) * (self.n_frames - 1)
+        est = FlowEstimatorReduce if self.reduce_dense else FlowEstimatorDense
+        self.flow_estimators = est(self.num_ch_in)
+        self.context_networks = ContextNetwork((self.flow_estimators.feat_dim + 2) * (self.n_frames - 1))
+        self.conv_1x1 = nn.ModuleList([conv(c, 32, kernel_size=1, stride=1, dilation=1)
+                                       for c in (192, 128, 96, 64, 32)])
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def init_weights(self):
+        init_conv_weights(self, 'kaiming')
+
+    def forward_2_frames(self, x1_pyramid, x2_pyramid):
+        """models/pwclite.py:161-204."""
+        flows = []
+        b, _, h, w = x1_pyramid[0].shape
+        flow = torch.zeros(b, 2, h, w, dtype=torch.float32, device=x1_pyramid[0].device)
+        for l, (x1, x2) in enumerate(zip(x1_pyramid, x2_pyramid)):
+            if l == 0:
+                x2_warp = x2
+            else:
+                flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
+                x2_warp = flow_warp(x2, flow)
+            out_corr_relu = self.leakyRELU(self.corr(x1, x2_warp))
+            x1_1by1 = self.conv_1x1[l](x1)
+            x_intm, flow_res = self.flow_estimators(torch.cat([out_corr_relu, x1_1by1, flow], dim=1))
+            flow = flow + flow_res
+            flow = flow + self.context_networks(torch.cat([x_intm, flow], dim=1))
+            flows.append(flow)
+            if l == self.output_level:
+                break
+        if self.upsample:
+            # only the finest flow is upsampled (models/pwclite.py:200-203) -> 6 outputs
+            flows.append(F.interpolate(flow * 4, scale_factor=4, mode='bilinear', align_corners=True))
+        return flows[::-1]
+
+    def forward_3_frames(self, x0_pyramid, x1_pyramid, x2_pyramid):
+        """models/pwclite.py:206-258 (multi-view: two warps + two correlations per level)."""
+        flows = []
+        b, _, h, w = x1_pyramid[0].shape
+        flow = torch.zeros(b, 4, h, w, dtype=torch.float32, device=x1_pyramid[0].device)
+        for l, (x0, x1, x2) in enumerate(zip(x0_pyramid, x1_pyramid, x2_pyramid)):
+            if l == 0:
+                x0_warp, x2_warp = x0, x2
+            else:
+                flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
+                x0_warp = flow_warp(x0, flow[:, :2])
+                x2_warp = flow_warp(x2, flow[:, 2:])
+            corr_relu_10 = self.leakyRELU(self.corr(x1, x0_warp))
+            corr_relu_12 = self.leakyRELU(self.corr(x1, x2_warp))
+            x1_1by1 = self.conv_1x1[l](x1)
+            feat_10 = [x1_1by1, corr_relu_10, corr_relu_12, flow[:, :2], -flow[:, 2:]]
+            feat_12 = [x1_1by1, corr_relu_12, corr_relu_10, flow[:, 2:], -flow[:, :2]]
+            x_intm_10, flow_res_10 = self.flow_estimators(torch.cat(feat_10, dim=1))
+            x_intm_12, flow_res_12 = self.flow_estimators(torch.cat(feat_12, dim=1))
+            flow = flow + torch.cat([flow_res_10, flow_res_12], dim=1)
+            feat_10 = [x_intm_10, x_intm_12, flow[:, :2], -flow[:, 2:]]
+            feat_12 = [x_intm_12, x_intm_10, flow[:, 2:], -flow[:, :2]]
+            flow_res_10 = self.context_networks(torch.cat(feat_10, dim=1))
+            flow_res_12 = self.context_networks(torch.cat(feat_12, dim=1))
+            flow = flow + torch.cat([flow_res_10, flow_res_12], dim=1)
+            flows.append(flow)
+            if l == self.output_level:
+                break
+        if self.upsample:
+            flows = [F.interpolate(f * 4, scale_factor=4, mode='bilinear', align_corners=True) for f in flows]
+        return [f[:, :2] for f in flows[::-1]], [f[:, 2:] for f in flows[::-1]]
+
+    def forward(self, x, with_bk=False):
+        """models/pwclite.py:260-283 -> {'flows_fw': [...], 'flows_bw': [...]} finest first."""
+        n_frames = x.size(1) // 3
+        imgs = [x[:, 3 * i: 3 * i + 3] for i in range(n_frames)]
+        B = x.size(0)
+        # one extractor pass over all frames (batch n*B) instead of n passes
+        pyr_all = self.feature_pyramid_extractor(torch.cat(imgs, 0))
+        pyrs = [[p[i * B:(i + 1) * B] for p in pyr_all] + [imgs[i]] for i in range(n_frames)]
+        res = {}
+        if n_frames == 2:
+            if with_bk:
+                a, b = pair_batches(pyrs[0], pyrs[1])
+                flows = self.forward_2_frames(a, b)
+                res['flows_fw'] = [f[:B] for f in flows]
+                res['flows_bw'] = [f[B:] for f in flows]
+            else:
+                res['flows_fw'] = self.forward_2_frames(pyrs[0], pyrs[1])
+        elif n_frames == 3:
+            flows_10, flows_12 = self.forward_3_frames(pyrs[0], pyrs[1], pyrs[2])
+            res['flows_fw'], res['flows_bw'] = flows_12, flows_10
+        elif n_frames == 5:
+            flows_10, flows_12 = self.forward_3_frames(pyrs[0], pyrs[1], pyrs[2])
+            flows_21, flows_23 = self.forward_3_frames(pyrs[1], pyrs[2], pyrs[3])
+            res['flows_fw'] = [flows_12, flows_23]
+            if with_bk:
+                flows_32, flows_34 = self.forward_3_frames(pyrs[2], pyrs[3], pyrs[4])
+                res['flows_bw'] = [flows_21, flows_32]
+        else:
+            raise NotImplementedError
+        return res

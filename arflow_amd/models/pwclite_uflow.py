@@ -1,0 +1,121 @@
+"""PWCLiteUflow host model on the gfx950 ops; contract of models/pwclite_uflow.py:126-267."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..correlation import Correlation
+from ..warp_utils import flow_warp
+from .blocks import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, FlowEstimatorReduce, deconv,
+                     init_conv_weights, pair_batches)
+
+
+def normalize_features(features_list):
+    """models/pwclite_uflow.py:30-38 -- per-sample moments of the channel-concatenated pair."""
+    n = sum(f[0].numel() for f in features_list)
+    s1 = sum(f.sum(dim=(-3, -2, -1), keepdim=True) for f in features_list)
+    mean = s1 / n
+    var = sum(((f - mean) ** 2).sum(dim=(-3, -2, -1), keepdim=True) for f in features_list) / (n - 1)
+    std = torch.sqrt(var + 1e-16)
+    return [(f - mean) / std for f in features_list]
+
+
+class PWCLiteUflow(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.search_range = 4
+        self.num_chs = [3, 16, 32, 32, 32, 32]
+        self.output_level = 3
+        self.num_levels = 6
+        self.deconv_chs = 32
+        self.level_dropout = cfg.level_dropout
+        self.leakyRELU = nn.LeakyReLU(0.1, inplace=True)
+        self.feature_norm = cfg.feature_norm
+        self.align_corners = cfg.align_corners
+        self.warp_pad = cfg.warp_pad
+        self.feature_pyramid_extractor = FeatureExtractor(self.num_chs, convs_per_level=3, rescale_input=True)
+        self.n_frames = cfg.n_frames
+        self.reduce_dense = cfg.reduce_dense
+        self.corr = Correlation(pad_size=self.search_range, kernel_size=1, max_displacement=self.search_range,
+                                stride1=1, stride2=1, corr_multiply=1)
+        self.dim_corr = (self.search_range * 2 + 1) ** 2
+        est = FlowEstimatorReduce if self.reduce_dense else FlowEstimatorDense
+        self.flow_estimators = nn.ModuleList()
+        for l, num in enumerate(self.num_chs[::-1][0:self.output_level + 1]):
+            ch_in = num + (self.dim_corr + 2) * (self.n_frames - 1) + (self.deconv_chs if l > 0 else 0)
+            self.flow_estimators.append(est(ch_in))
+        self.context_networks = ContextNetwork(
+            (self.flow_estimators[self.output_level].feat_dim + 2) * (self.n_frames - 1))
+        self.deconv_networks = nn.ModuleList(
+            [deconv(e.feat_dim, self.deconv_chs) for e in self.flow_estimators[0:self.output_level]])
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def init_weights(self):
+        init_conv_weights(self, 'xavier')
+
+    def _drops(self, n_passes, batch_per_pass, device):
+        """Level-dropout multipliers, drawn from the CPU RNG in the reference's order (per pass:
+        one per level, then one for the context net; models/pwclite_uflow.py:226-229,240-242)."""
+        n = self.output_level + 2
+        if not (self.training and self.level_dropout > 0):
+            return None
+        vals = [[float(torch.rand(1) > self.level_dropout) for _ in range(n)] for _ in range(n_passes)]
+        t = torch.tensor(vals, dtype=torch.float32)                      # [passes, n]
+        t = t.repeat_interleave(batch_per_pass, dim=0).t().contiguous()  # [n, passes*B]
+        return t.to(device, non_blocking=True).view(n, -1, 1, 1, 1)
+
+    def forward_2_frames(self, x1_pyramid, x2_pyramid, drops=None):
+        """models/pwclite_uflow.py:193-252."""
+        flows = []
+        b, _, h, w = x1_pyramid[0].shape
+        flow = torch.zeros(b, 2, h, w, dtype=torch.float32, device=x1_pyramid[0].device)
+        act = None
+        levels = list(zip(x1_pyramid[0:self.output_level + 1], x2_pyramid[0:self.output_level + 1]))
+        for l, (x1, x2) in enumerate(levels):
+            if l == 0:
+                x2_warp = x2
+            else:
+                flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=self.align_corners)
+                x2_warp = flow_warp(x2, flow, align_corners=self.align_corners, pad=self.warp_pad)
+            if self.feature_norm:
+                x1, x2_warp = normalize_features([x1, x2_warp])
+            out_corr_relu = self.leakyRELU(self.corr(x1, x2_warp))
+            if l == 0:
+                act, flow_res = self.flow_estimators[l](torch.cat([out_corr_relu, x1, flow], dim=1))
+            else:
+                act_deconv = self.deconv_networks[l - 1](act)
+                act, flow_res = self.flow_estimators[l](torch.cat([out_corr_relu, x1, flow, act_deconv], dim=1))
+            if drops is not None:
+                flow_res = flow_res * drops[l]
+                act = act * drops[l]
+            flow = flow + flow_res
+            flows.append(flow)
+        flow_fine = self.context_networks(torch.cat([act, flow], dim=1))
+        if drops is not None:
+            flow_fine = flow_fine * drops[len(levels)]
+        flow = flow + flow_fine
+        flows[-1] = flow
+        for _ in range(2):
+            flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=self.align_corners)
+            flows.append(flow)
+        return flows[::-1]
+
+    def forward(self, x, with_bk=False):
+        n_frames = x.size(1) // 3
+        if n_frames != 2:
+            raise NotImplementedError
+        B = x.size(0)
+        imgs = [x[:, 0:3], x[:, 3:6]]
+        pyr_all = self.feature_pyramid_extractor(torch.cat(imgs, 0))
+        p1 = [p[:B] for p in pyr_all] + [imgs[0]]
+        p2 = [p[B:] for p in pyr_all] + [imgs[1]]
+        res = {}
+        if with_bk:
+            a, b = pair_batches(p1, p2)
+            flows = self.forward_2_frames(a, b, self._drops(2, B, x.device))
+            res['flows_fw'] = [f[:B] for f in flows]
+            res['flows_bw'] = [f[B:] for f in flows]
+        else:
+            res['flows_fw'] = self.forward_2_frames(p1, p2, self._drops(1, B, x.device))
+        return res

@@ -1,0 +1,169 @@
+"""PWCFlow (UFlow port) host model on the gfx950 ops; contract of models/uflow_model.py:96-470.
+This is what configs/chairs_uflow.json instantiates (``"model": {"type": "uflow"}``)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as func
+
+from .. import uflow_utils
+from ..correlation import compute_cost_volume
+from .blocks import init_conv_weights, pair_batches
+
+
+def normalize_features(feature_list, normalize, center, moments_across_channels, moments_across_images):
+    """models/uflow_model.py:8-50."""
+    dim = [1, 2, 3] if moments_across_channels else [2, 3]
+    means = [f.mean(dim=dim, keepdim=True) for f in feature_list]
+    vars_ = [f.var(dim=dim, keepdim=True) for f in feature_list]
+    if moments_across_images:
+        means = [torch.stack(means).mean(0)] * len(means)
+        vars_ = [torch.stack(vars_).mean(0)] * len(vars_)
+    stds = [torch.sqrt(v + 1e-16) for v in vars_]
+    if center:
+        feature_list = [f - m for f, m in zip(feature_list, means)]
+    if normalize:
+        feature_list = [f / s for f, s in zip(feature_list, stds)]
+    return feature_list
+
+
+class PWCFeaturePyramid(nn.Module):
+    """models/uflow_model.py:350-470 with the defaults PWCFlow uses: 5 levels of three 3x3 VALID convs
+    (explicit zero pad 1), 32 filters, stride 2 on the first conv of each level, LeakyReLU(0.1)."""
+
+    def __init__(self, leaky_relu_alpha=0.1, num_levels=5, num_channels=3):
+        super().__init__()
+        self._leaky_relu_alpha = leaky_relu_alpha
+        self._convs = nn.ModuleList()
+        c = num_channels
+        for _ in range(num_levels):
+            group = nn.ModuleList()
+            for i in range(3):
+                group.append(nn.Conv2d(c, 32, kernel_size=(3, 3), stride=2 if i == 0 else 1, padding='valid'))
+                c = 32
+            self._convs.append(group)
+
+    def forward(self, x):
+        x = x * 2. - 1.
+        features = []
+        for group in self._convs:
+            for conv in group:
+                x = func.pad(x, pad=[1, 1, 1, 1], mode='constant', value=0)
+                x = func.leaky_relu(conv(x), negative_slope=self._leaky_relu_alpha)
+            features.append(x)
+        return features
+
+
+class PWCFlow(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self._leaky_relu_alpha = 0.1
+        self._drop_out_rate = cfg.level_dropout
+        self._num_context_up_channels = 32
+        self._num_levels = 5
+        self._normalize_before_cost_volume = cfg.feature_norm
+        # registration order matters for state_dict order: refine, flow layers, upsample, pyramid
+        self._refine_model = self._build_refinement_model()
+        self._flow_layers = self._build_flow_layers()
+        self._context_up_layers = nn.ModuleList(
+            [nn.ConvTranspose2d(32, 32, kernel_size=(4, 4), stride=2, padding=1) for _ in range(self._num_levels)])
+        self._feature_pyramid_extractor = PWCFeaturePyramid()
+
+    def init_weights(self):
+        init_conv_weights(self, 'xavier')
+
+    def _build_flow_layers(self):
+        """models/uflow_model.py:297-323: per level 5 dense 3x3 blocks (128,128,96,64,32) and a 32->2
+        head that sees only the last block."""
+        result = nn.ModuleList([None])
+        for i in range(1, self._num_levels):
+            layers = nn.ModuleList()
+            c_in = 81 + 32 + (0 if i == self._num_levels - 1 else 2 + self._num_context_up_channels)
+            for c in (128, 128, 96, 64, 32):
+                layers.append(nn.Sequential(nn.Conv2d(c_in, c, kernel_size=(3, 3), stride=1, padding='same'),
+                                            nn.LeakyReLU(negative_slope=self._leaky_relu_alpha)))
+                c_in += c
+            layers.append(nn.Conv2d(32, 2, kernel_size=(3, 3), padding='same'))
+            result.append(layers)
+        return result
+
+    def _build_refinement_model(self):
+        """models/uflow_model.py:325-348."""
+        layers = []
+        c_in = 32 + 2
+        for c, d in [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1)]:
+            layers.append(nn.Conv2d(c_in, c, kernel_size=(3, 3), stride=1, padding='same', dilation=d))
+            layers.append(nn.LeakyReLU(negative_slope=self._leaky_relu_alpha))
+            c_in = c
+        layers.append(nn.Conv2d(c_in, 2, kernel_size=(3, 3), stride=1, padding='same'))
+        return nn.ModuleList(layers)
+
+    def _drops(self, n_passes, batch_per_pass, device):
+        n = (self._num_levels - 1) + 1  # one per level 4..1, then one for the refinement
+        if not (self.training and self._drop_out_rate > 0):
+            return None
+        vals = [[float(torch.rand(1) > self._drop_out_rate) for _ in range(n)] for _ in range(n_passes)]
+        t = torch.tensor(vals, dtype=torch.float32).repeat_interleave(batch_per_pass, dim=0).t().contiguous()
+        return t.to(device, non_blocking=True).view(n, -1, 1, 1, 1)
+
+    def forward_2_frames(self, feature_pyramid1, feature_pyramid2, drops=None):
+        """models/uflow_model.py:138-245."""
+        context = flow = flow_up = context_up = None
+        flows = []
+        k = 0
+        for level in range(self._num_levels - 1, 0, -1):
+            features1, features2 = feature_pyramid1[level], feature_pyramid2[level]
+            if flow_up is None:
+                warped2 = features2
+            else:
+                warped2 = uflow_utils.resample_flow(features2, flow_up)  # resample(f2, flow_to_warp(flow_up))
+            f1n, w2n = normalize_features([features1, warped2], normalize=self._normalize_before_cost_volume,
+                                          center=self._normalize_before_cost_volume,
+                                          moments_across_channels=True, moments_across_images=True)
+            cost_volume = func.leaky_relu(compute_cost_volume(f1n, w2n, max_displacement=4),
+                                          negative_slope=self._leaky_relu_alpha)
+            if flow_up is None:
+                x_in = torch.cat([cost_volume, features1], dim=1)
+            else:
+                x_in = torch.cat([context_up, flow_up, cost_volume, features1], dim=1)
+            layers = self._flow_layers[level]
+            x_out = None
+            for layer in layers[:-1]:
+                x_out = layer(x_in)
+                x_in = torch.cat([x_in, x_out], dim=1)
+            context = x_out
+            flow = layers[-1](context)
+            if drops is not None:
+                context = context * drops[k]
+                flow = flow * drops[k]
+            k += 1
+            if flow_up is not None:
+                flow = flow + flow_up
+            flow_up = uflow_utils.upsample(flow, is_flow=True)
+            context_up = self._context_up_layers[level](context)
+            flows.insert(0, flow)
+        refinement = torch.cat([context, flow], dim=1)
+        for layer in self._refine_model:
+            refinement = layer(refinement)
+        if drops is not None:
+            refinement = refinement * drops[k]
+        flows[0] = flow + refinement
+        flows.insert(0, uflow_utils.upsample(flows[0], is_flow=True))
+        flows.insert(0, uflow_utils.upsample(flows[0], is_flow=True))
+        return flows
+
+    def forward(self, x, with_bk=True):
+        n_frames = x.size(1) // 3
+        if n_frames != 2:
+            raise NotImplementedError
+        B = x.size(0)
+        pyr_all = self._feature_pyramid_extractor(torch.cat([x[:, 0:3], x[:, 3:6]], 0))
+        p1 = [p[:B] for p in pyr_all]
+        p2 = [p[B:] for p in pyr_all]
+        res = {}
+        if with_bk:
+            a, b = pair_batches(p1, p2)
+            flows = self.forward_2_frames(a, b, self._drops(2, B, x.device))
+            res['flows_fw'] = [f[:B] for f in flows]
+            res['flows_bw'] = [f[B:] for f in flows]
+        else:
+            res['flows_fw'] = self.forward_2_frames(p1, p2, self._drops(1, B, x.device))
+        return res

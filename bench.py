@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the ARFlow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--size H W] [--batch B]
+
+One "step" = one full pass of the hot path over one batch of synthetic image pairs: model forward for
+both flow directions (cost-volume correlation + bilinear warp at every pyramid level, HIP kernels),
+the unsupervised loss (census / occlusion splat / smoothness, HIP kernels), backward through all of it,
+gradient all-reduce (N > 1) and the Adam update.  Default workload = BASELINE.json configs[1]:
+384x640 pairs, batch 8 per GPU (weak scaling), fp32.  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+
+For N > 1 launch with:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+                        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(name, shape):
+    """Compulsory HBM bytes of one launch (each input read once, each output written once, fp32):
+    SURVEY section 8(d).  `shape` is the tuple recorded by arflow_amd.functional for the call."""
+    if name == 'arflow_corr_fwd':
+        B, C, H, W, d = shape
+        return 4 * B * H * W * (2 * C + (2 * d + 1) ** 2)
+    if name == 'arflow_corr_bwd':
+        B, C, H, W, d = shape
+        return 4 * B * H * W * ((2 * d + 1) ** 2 + 4 * C)
+    if name == 'arflow_warp_fwd':
+        B, C, H, W = shape
+        return 4 * B * H * W * (2 * C + 2)
+    if name == 'arflow_warp_bwd':
+        B, C, H, W, with_src = shape
+        return 4 * B * H * W * ((3 * C + 4) if with_src else (2 * C + 4))
+    if name == 'arflow_census_fwd':
+        B, H, W = shape
+        return 4 * B * H * W * (3 + 3 + 1 + 1)
+    if name == 'arflow_census_bwd':
+        B, H, W = shape
+        return 4 * B * H * W * (3 + 3 + 1 + 3)
+    if name == 'arflow_photo_fwd':
+        B, C, H, W = shape
+        return 4 * B * H * W * (2 * C + 1)
+    if name == 'arflow_photo_bwd':
+        B, C, H, W = shape
+        return 4 * B * H * W * (3 * C + 1)
+    if name in ('arflow_smooth_fwd', 'arflow_smooth_bwd'):
+        B, Ci, H, W = shape
+        return 4 * B * H * W * (2 + Ci + (2 if name.endswith('bwd') else 0))
+    if name in ('arflow_splat_map', 'arflow_coord_mask'):
+        B, H, W = shape
+        return 4 * B * H * W * 3
+    if name == 'arflow_occ_bidir':
+        B, H, W = shape
+        return 4 * B * H * W * 5
+    if name == 'arflow_down4':
+        P, H, W = shape
+        return 4 * P * H * W * (1 + 1 / 16)
+    if name == 'arflow_up4_clamp_mul':
+        B, h, w = shape
+        return 4 * B * h * w * (1 + 16 + 16)
+    return 0
+
+
+def cpu_baseline(workload, height, width, budget_s=25.0):
+    """The oracle (CPU restatement, kind 'port') on this host's cores: same workload shape, bounded
+    sample (batch 1, a few steps).  Baseline only -- never the thing shipped."""
+    from oracle import losses as OL  # checker / baseline only
+    from oracle.host_models import oracle_ops
+    from arflow_amd.train_step import WORKLOADS, synthetic_pairs
+    from arflow_amd.config import AttrDict
+    from arflow_amd.models import get_model
+    mcfg, lcfg = WORKLOADS[workload]
+    torch.manual_seed(0)
+    model = get_model(AttrDict(mcfg))
+    model.init_weights()
+    model.train()
+    loss_cls = {'uflow': OL.UFlowLoss, 'unflow': OL.unFlowLoss, 'fullres': OL.FullResLoss}[lcfg['type']]
+    loss = loss_cls(AttrDict(lcfg))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    B = 1
+    x = synthetic_pairs(B, height, width, device='cpu')
+    cores = torch.get_num_threads()
+    times = []
+    with oracle_ops(model):
+        t_start = time.time()
+        for it in range(4):
+            t0 = time.time()
+            res = model(x, with_bk=True)
+            flows = [torch.cat([a, b], 1) for a, b in zip(res['flows_fw'], res['flows_bw'])]
+            out = loss(flows, x)
+            opt.zero_grad()
+            out[0].backward()
+            opt.step()
+            dt = time.time() - t0
+            if it > 0:
+                times.append(dt)
+            if time.time() - t_start > budget_s and times:
+                break
+    per_step = sum(times) / len(times)
+    return {'value': B / per_step, 'unit': 'image-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle/ (pure-PyTorch CPU restatement) full step (fwd+bwd+Adam) of %s at batch %d, %dx%d, '
+                      '%d timed step(s) after 1 warm-up, torch threads=%d' % (workload, B, height, width, len(times), cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='pwclite_uflow+uflow_loss')
+    ap.add_argument('--size', type=int, nargs=2, default=[384, 640])
+    ap.add_argument('--batch', type=int, default=8, help='image pairs per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched through torch.distributed.run with %d ranks '
+                     '(see the module docstring)' % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=device)
+
+    from arflow_amd import functional as AF
+    from arflow_amd.train_step import TrainStep, synthetic_pairs
+
+    H, W = args.size
+    step = TrainStep(args.workload, device, seed=1234)
+    torch.manual_seed(1000 + rank)  # level-dropout draws differ per rank, like independent workers
+    img = synthetic_pairs(args.batch, H, W, device=device, seed=100 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(img)
+    sync()
+    if not args.no_kernel_timing:
+        AF.start_kernel_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(img)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timing = AF.stop_kernel_timing() if not args.no_kernel_timing else {}
+    finite = bool(torch.isfinite(step.last).item())
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        line = {
+            'metric': 'image-pairs/sec fwd+bwd, PWCLite 384x640 bs=8',
+            'value': pairs / elapsed, 'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s, %dx%d pairs, batch %d per GPU, fwd(both directions)+loss+bwd+allreduce+Adam'
+                                   % (args.workload, H, W, args.batch),
+                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'loss_finite': finite},
+        }
+        # dominant hot-path kernel by accumulated device time (HIP events around every launch)
+        per = {}
+        for (name, shape), durs in timing.items():
+            per[(name, shape)] = (sum(durs), len(durs))
+        if per:
+            (name, shape), (tot, n) = max(per.items(), key=lambda kv: kv[1][0])
+            avg_ms = tot / n
+            nbytes = algorithmic_bytes(name, shape)
+            ach = nbytes / (avg_ms * 1e-3) / 1e9
+            line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': ach / HBM_PEAK_GBS, 'traffic': None, 'kernel': name, 'shape': list(shape),
+                                'avg_us': 1e3 * avg_ms, 'launches_per_step': n / args.steps,
+                                'algorithmic_bytes': nbytes}
+            hot_ms = sum(v[0] for v in per.values()) / args.steps
+            hot_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in per.items()) / args.steps
+            line['hot_path'] = {'ms_per_step': hot_ms, 'algorithmic_GB_per_step': hot_bytes / 1e9,
+                                'GBps': hot_bytes / (hot_ms * 1e-3) / 1e9,
+                                'frac_of_hbm_peak': hot_bytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'share_of_step': hot_ms / (1e3 * elapsed / args.steps),
+                                'kernels': {('%s%s' % (k[0], list(k[1]))): {'us': 1e3 * v[0] / v[1], 'n': v[1] / args.steps,
+                                                                           'GBps': algorithmic_bytes(k[0], k[1]) / (v[0] / v[1] * 1e-3) / 1e9}
+                                            for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:12]}}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(args.workload, H, W)
+            except Exception as e:  # never lose the GPU number because the baseline leg failed
+                line['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

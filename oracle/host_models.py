@@ -1,0 +1,42 @@
+"""Run the product's HOST model classes (arflow_amd/models: conv pyramids, decoders, wiring) with the
+ORACLE ops substituted for the HIP ops, on the CPU.  Used by tests (host-logic parity against the
+reference's golden flows) and by bench.py's ``cpu_baseline`` leg.  TEST INFRASTRUCTURE ONLY: the
+substitution is made from here, the product never selects it."""
+import contextlib
+
+import torch.nn as nn
+
+from . import ops as O
+
+
+class OracleCorrelation(nn.Module):
+    def __init__(self, d=4):
+        super().__init__()
+        self.d = d
+
+    def forward(self, x1, x2):
+        return O.correlation(x1, x2, self.d)
+
+
+@contextlib.contextmanager
+def oracle_ops(model):
+    import arflow_amd.models.pwclite as mp
+    import arflow_amd.models.pwclite_uflow as mpu
+    import arflow_amd.models.uflow_model as mum
+    saved = [(mp, 'flow_warp', mp.flow_warp), (mpu, 'flow_warp', mpu.flow_warp),
+             (mum, 'compute_cost_volume', mum.compute_cost_volume),
+             (mum.uflow_utils, 'resample_flow', mum.uflow_utils.resample_flow)]
+    old_corr = getattr(model, 'corr', None)
+    try:
+        mp.flow_warp = O.flow_warp
+        mpu.flow_warp = O.flow_warp
+        mum.compute_cost_volume = lambda a, b, max_displacement: O.correlation(a, b, max_displacement)
+        mum.uflow_utils.resample_flow = lambda src, flow: O.resample(src, O.flow_to_warp(flow))
+        if old_corr is not None:
+            model.corr = OracleCorrelation(4)
+        yield model
+    finally:
+        for mod, name, val in saved:
+            setattr(mod, name, val)
+        if old_corr is not None:
+            model.corr = old_corr

@@ -24,10 +24,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 # the script's own directory must not shadow the reference's top-level packages (losses/, models/)
 sys.path[:] = [p for p in sys.path if os.path.abspath(p or '.') != HERE]
-
-
-class Cfg(dict):
-    __getattr__ = dict.__getitem__
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.fixture_common import Cfg, fill_deterministic, loss_cfgs, pool_to_quarter, synth_pair  # noqa: E402
 
 
 def field(B, C, H, W, a, b, c, d):
@@ -202,40 +200,6 @@ def gen_ops():
     save('aux', **out)
 
 
-def loss_cfgs():
-    uflow = [('uflow_o1', Cfg(type='uflow', edge_constant=150, w_smooth=4.0, w_census=1.0, with_bk=True, smooth_order=1)),
-             ('uflow_o2', Cfg(type='uflow', edge_constant=150, w_smooth=2.0, w_census=1.0, with_bk=True, smooth_order=2)),
-             ('uflow_nobk', Cfg(type='uflow', edge_constant=150, w_smooth=4.0, w_census=1.0, with_bk=False, smooth_order=1))]
-    unflow = [('unflow_back', Cfg(type='unflow', w_l1=0.15, w_ssim=0.85, w_ternary=0.0, warp_pad='border', alpha=10,
-                                   occ_from_back=True, with_bk=True, w_smooth=75.0,
-                                   w_scales=[1.0, 1.0, 1.0, 1.0, 0.0], w_sm_scales=[1.0, 0.0, 0.0, 0.0, 0.0])),
-              ('unflow_bidir_2nd', Cfg(type='unflow', w_l1=0.15, w_ssim=0.85, w_ternary=0.0, warp_pad='zeros', alpha=10,
-                                        occ_from_back=False, with_bk=True, w_smooth=50.0, smooth_2nd=True,
-                                        w_scales=[1.0, 0.5, 1.0, 1.0, 1.0], w_sm_scales=[1.0, 0.5, 0.0, 0.0, 0.0])),
-              ('unflow_l1only_nobk', Cfg(type='unflow', w_l1=1.0, w_ssim=0.0, w_ternary=0.0, warp_pad='border', alpha=10,
-                                          occ_from_back=True, with_bk=False, w_smooth=10.0,
-                                          w_scales=[1.0, 1.0, 0.0, 0.0, 0.0], w_sm_scales=[1.0, 1.0, 0.0, 0.0, 0.0]))]
-    full = [('fullres_wang', Cfg(type='fullres', w_l1=0.5, w_ssim=0.0, w_ternary=1.0, ternary_distance=3, warp_pad='zeros',
-                                  align_corners=True, occ_type='wang', wang_thr=0.2, with_bk=True, alpha=10, w_smooth=4.0)),
-            ('fullres_wang1', Cfg(type='fullres', w_l1=0.0, w_ssim=0.0, w_ternary=1.0, ternary_distance=3, warp_pad='border',
-                                   align_corners=False, occ_type='wang1', with_bk=True, alpha=10, w_smooth=4.0)),
-            ('fullres_brox', Cfg(type='fullres', w_l1=1.0, w_ssim=0.0, w_ternary=0.5, ternary_distance=1, warp_pad='zeros',
-                                  align_corners=True, occ_type='brox', with_bk=True, alpha=10, w_smooth=2.0))]
-    return uflow, unflow, full
-
-
-def synth_pair(B, H, W, rng):
-    """Smooth-ish image pair + 5-level flow pyramid (full, 1/2, 1/4, 1/8, 1/16)."""
-    base = torch.rand(B, 6, H // 4, W // 4, generator=rng)
-    img = torch.nn.functional.interpolate(base, (H, W), mode='bilinear', align_corners=False)
-    img = (img + 0.15 * torch.rand(B, 6, H, W, generator=rng)).clamp(0, 1)
-    flows = []
-    for s in (1, 2, 4, 8, 16):
-        f = torch.randn(B, 4, H // s, W // s, generator=rng) * (4.0 / s)
-        flows.append(f)
-    return img, flows
-
-
 def gen_losses():
     from losses.uflow_loss import UFlowLoss
     from losses.flow_loss import unFlowLoss
@@ -262,28 +226,6 @@ def gen_losses():
     save('losses', **out)
 
 
-def fill_deterministic(model):
-    """Deterministic, construction-order-independent weights: depends only on key name + shape.
-
-    Used instead of seeded init so that the product's host model (different construction code)
-    can be given bit-identical weights without shipping a 9-29 MB state_dict."""
-    import zlib
-    sd = model.state_dict()
-    for key in sorted(sd.keys()):
-        t = sd[key]
-        n = t.numel()
-        h = zlib.crc32(key.encode()) % 1000
-        idx = torch.arange(n, dtype=torch.float64)
-        if key.endswith('bias'):
-            v = 0.02 * torch.sin(0.731 * idx + h)
-        else:
-            fan_in = t[0].numel() if t.dim() > 1 else 1
-            v = torch.sin(0.37 * idx + 0.11 * h) * (1.7 / fan_in) ** 0.5
-        sd[key] = v.float().view_as(t)
-    model.load_state_dict(sd)
-    return model
-
-
 def gen_models():
     import models.pwclite as mp
     import models.pwclite_uflow as mpu
@@ -297,12 +239,12 @@ def gen_models():
         fill_deterministic(model)
         model.eval()
         res = model(x, with_bk=with_bk)
-        out = {tag + '_x': x, tag + '_nparams': sum(p.numel() for p in model.parameters()),
+        out = {tag + '_nparams': sum(p.numel() for p in model.parameters()),
                tag + '_keys': np.array(list(model.state_dict().keys()))}
         for k in ('flows_fw', 'flows_bw'):
             if k in res:
                 for i, f in enumerate(res[k]):
-                    out['%s_%s_%d' % (tag, k, i)] = f
+                    out['%s_%s_%d' % (tag, k, i)] = pool_to_quarter(f, x.shape[2])
         if loss is not None:
             flows = [torch.cat([a, b], 1) for a, b in zip(res['flows_fw'], res['flows_bw'])]
             lres = loss(flows, x)
@@ -319,9 +261,11 @@ def gen_models():
             out[tag + '_gabs'] = np.array(ga)
         return out
 
-    out = {}
-    x2 = synth_pair(1, 128, 192, rng)[0]
-    x3 = torch.cat([x2, synth_pair(1, 128, 192, rng)[0][:, :3]], 1)
+    x2 = synth_pair(1, 192, 256, rng)[0]
+    x3 = torch.cat([x2, synth_pair(1, 192, 256, rng)[0][:, :3]], 1)
+    out = {'x3': (x3 * 255).round().to(torch.uint8)}  # 8-bit images: x = uint8/255; x2 = x3[:, :6]
+    x3 = out['x3'].float() / 255
+    x2 = x3[:, :6].contiguous()
     cfg_unflow6 = Cfg(dict(unflow[0][1]))
     cfg_unflow6['w_scales'] = [1.0, 1.0, 1.0, 1.0, 1.0, 0.0]
     cfg_unflow6['w_sm_scales'] = [1.0, 0.0, 0.0, 0.0, 0.0, 0.0]

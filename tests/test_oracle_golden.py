@@ -162,15 +162,8 @@ def test_resize_and_normalisation(golden):
 
 
 def _loss_cases():
-    import importlib.util
-    import os
-    spec = importlib.util.spec_from_file_location(
-        'make_golden', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'oracle', 'make_golden.py'))
-    mod = importlib.util.module_from_spec(spec)
-    saved = list(__import__('sys').path)
-    spec.loader.exec_module(mod)
-    __import__('sys').path[:] = saved
-    return mod.loss_cfgs()
+    from oracle.fixture_common import loss_cfgs
+    return loss_cfgs()
 
 
 @pytest.mark.parametrize('group', [0, 1, 2])
