@@ -53,6 +53,13 @@ __device__ __forceinline__ void af_block_sum(float (&v)[NV], float* scratch) {
   }
 }
 
+// Row of the slotted `sums` buffer this workgroup adds into (see ARFLOW_NSLOT in the header).
+__device__ __forceinline__ float* af_sum_slot(float* sums) {
+  const unsigned s = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) % ARFLOW_NSLOT;
+  return sums + s * ARFLOW_SLOT_STRIDE;
+}
+#define AF_SUMS_BYTES (sizeof(float) * ARFLOW_NSLOT * ARFLOW_SLOT_STRIDE)
+
 // torch grid_sample un-normalisation (ATen/native/GridSampler.h:27-36).
 __device__ __forceinline__ float af_unnormalize(float g, int size, bool align) {
   return align ? ((g + 1.f) / 2.f) * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) / 2.f;

@@ -1,0 +1,270 @@
+// Fast path of the cost-volume kernels for the configuration every model uses (max_disp = 4) when
+// W % 4 == 0 and C % 4 == 0.  See corr.hip for the arithmetic and the generic kernels.
+//
+// One workgroup = 3 waves over one 8 x 32 pixel tile.  Wave w owns the row shifts i = 3w..3w+2; a
+// lane owns 4 consecutive pixels of one tile row.
+//   * staging: the operand tile (+4 px halo: 16 rows x 40 floats) of 4 channels is brought in by
+//     LDS-DMA (global_load_lds_dwordx4: per-lane global address, linear LDS destination) into a
+//     double buffer, issued one chunk ahead of the FMAs -- no staging VGPRs, one barrier per chunk.
+//     The halo outside the image is never written: LDS is zero-filled once and out-of-image lanes are
+//     masked off for every chunk (the pattern depends on the tile only).
+//   * the lane -> (pixel group, row) map is a bit permutation chosen so that every ds_read_b128 of a
+//     12-float window row is bank-conflict free with the native 40-float pitch (searched offline
+//     against the gfx950 b128 lane groups).
+//   * forward: 3 x 9 x 4 accumulators per lane; per channel 1 + 9 b128 LDS reads feed 108 FMAs.
+//   * backward: the lane keeps its 3 x 9 x 4 output gradients in VGPRs for the whole kernel (gout is
+//     read once); per channel it produces a 4-pixel partial sum over its 27 displacements, the three
+//     waves' partials meet in LDS and are summed + stored by the workgroup.
+#pragma once
+#include "common.hpp"
+
+namespace corr_v2 {
+
+constexpr int D = 4, N = 9, PX = 4, TW = 32, TH = 8, CC = 4, NW = 3, NT = 64 * NW;
+constexpr int SR = TH + 2 * D;           // 16 staged rows
+constexpr int SP = TW + 2 * D;           // 40 floats: row pitch of both staged tiles
+constexpr int SRC_FLOATS = CC * SR * SP;  // 2560 = 10 wave-wide DMA instructions
+constexpr int X1_FLOATS = CC * TH * SP;   // 1280 = 5  (32 of 40 floats used: pitch kept for banking)
+constexpr int SRC_DMA = SRC_FLOATS / 256, X1_DMA = X1_FLOATS / 256;
+
+__device__ __forceinline__ void lane_xy(int lane, int& xg, int& y) {
+  xg = ((lane >> 2) & 1) | (((lane >> 3) & 1) << 1) | ((lane & 1) << 2);
+  y = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2);
+}
+
+__device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Descriptor of the 16-byte piece this lane moves in wave-wide DMA instruction `k` of a staged
+// region with `rows` rows per channel: element offset inside the [C,H,W] image (relative to channel
+// c0) or -1 when the piece lies outside the image / in the pad columns.
+__device__ __forceinline__ int piece_offset(int k, int lane, int rows, int used_slots, int gy0, int gx0,
+                                            int H, int W) {
+  const int s = k * 64 + lane;
+  const int per_c = rows * (SP / 4);
+  const int c = s / per_c, rem = s - c * per_c;
+  const int r = rem / (SP / 4), xs = rem - r * (SP / 4);
+  const int gy = gy0 + r, gx = gx0 + 4 * xs;
+  if (xs >= used_slots || gy < 0 || gy >= H || gx < 0 || gx >= W) return -1;
+  return (c * H + gy) * W + gx;
+}
+
+__device__ __forceinline__ void zero_lds(float* lds, int nfloats) {
+  for (int i = threadIdx.x * 4; i < nfloats; i += NT * 4)
+    *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void load_window(const float* row, float (&w)[PX + 2 * D]) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(row + 4 * q);
+    w[4 * q] = t.x, w[4 * q + 1] = t.y, w[4 * q + 2] = t.z, w[4 * q + 3] = t.w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                    float* __restrict__ out, int C, int H, int W, float inv_c) {
+  constexpr int BUF = SRC_FLOATS + X1_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int xg, y;
+  lane_xy(lane, xg, y);
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, b = blockIdx.z;
+  const long cs = (long)H * W;
+  const float* x1b = x1 + (long)b * C * cs;
+  const float* x2b = x2 + (long)b * C * cs;
+
+  // this wave issues DMA instructions k = wave, wave+3, ... of the 15 per chunk (10 x2 + 5 x1)
+  constexpr int NK = (SRC_DMA + X1_DMA) / NW;  // 5
+  int off[NK];
+#pragma unroll
+  for (int m = 0; m < NK; ++m) {
+    const int k = wave + NW * m;
+    off[m] = k < SRC_DMA ? piece_offset(k, lane, SR, SP / 4, ty0 - D, tx0 - D, H, W)
+                         : piece_offset(k - SRC_DMA, lane, TH, TW / 4, ty0, tx0, H, W);
+  }
+  auto issue = [&](int c0, float* buf) {
+#pragma unroll
+    for (int m = 0; m < NK; ++m) {
+      const int k = wave + NW * m;
+      const float* g = (k < SRC_DMA ? x2b : x1b) + (long)c0 * cs;
+      float* dst = buf + k * 256;  // x1 region follows the x2 region: block index k carries over
+      if (off[m] >= 0) dma16(g + off[m], dst);
+    }
+  };
+
+  zero_lds(lds, 2 * BUF);
+  __syncthreads();
+  issue(0, lds);
+
+  float acc[3][N][PX];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+      for (int p = 0; p < PX; ++p) acc[k][j][p] = 0.f;
+
+  const int nchunk = C / CC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    float* cur = lds + (ch & 1) * BUF;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk `ch` has landed for every wave; buffer (ch+1)&1 is no longer being read
+    if (ch + 1 < nchunk) issue((ch + 1) * CC, lds + ((ch + 1) & 1) * BUF);
+    const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
+    const float* s1 = cur + SRC_FLOATS + y * SP + 4 * xg;
+#pragma unroll 1
+    for (int c = 0; c < CC; ++c) {
+      const float4 av = *reinterpret_cast<const float4*>(s1 + c * TH * SP);
+      const float a[PX] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float w[PX + 2 * D];
+        load_window(s2 + (c * SR + k) * SP, w);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+          for (int p = 0; p < PX; ++p) acc[k][j][p] = fmaf(a[p], w[j + p], acc[k][j][p]);
+      }
+    }
+  }
+
+  const int gy = ty0 + y, gx = tx0 + 4 * xg;
+  if (gy >= H || gx >= W) return;
+  float* ob = out + (((long)b * N * N + 3 * wave * N) * H + gy) * W + gx;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      *reinterpret_cast<float4*>(ob + (k * N + j) * cs) =
+          make_float4(acc[k][j][0] * inv_c, acc[k][j][1] * inv_c, acc[k][j][2] * inv_c, acc[k][j][3] * inv_c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mode 0: gx1[c,p] = (1/C) sum_{i,j} g[i*9+j][p]        * x2[c][p+(i-4,j-4)]
+// mode 1: gx2[c,q] = (1/C) sum_{i,j} g[80-(i*9+j)][q+(i-4,j-4)] * x1[c][q+(i-4,j-4)]
+__global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x1,
+                                                    const float* __restrict__ x2, float* __restrict__ gx1,
+                                                    float* __restrict__ gx2, int B, int C, int H, int W,
+                                                    float inv_c, int mode_base) {
+  constexpr int BUF = SRC_FLOATS;
+  constexpr int PART = NW * CC * 64 * PX;  // 3072 floats
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF + PART];
+  float* part = lds + 2 * BUF;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int xg, y;
+  lane_xy(lane, xg, y);
+  const int mode = mode_base + (int)(blockIdx.z / B);
+  const int b = blockIdx.z % B;
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  const long cs = (long)H * W;
+  const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * cs;
+  float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * cs;
+  const float* gb = gout + (long)b * N * N * cs;
+  const int gy = ty0 + y, gx = tx0 + 4 * xg;
+
+  constexpr int NK = (SRC_DMA + NW - 1) / NW;  // 4 (wave 0) / 3
+  int off[NK];
+#pragma unroll
+  for (int m = 0; m < NK; ++m) {
+    const int k = wave + NW * m;
+    off[m] = k < SRC_DMA ? piece_offset(k, lane, SR, SP / 4, ty0 - D, tx0 - D, H, W) : -1;
+  }
+  auto issue = [&](int c0, float* buf) {
+    const float* g = srcb + (long)c0 * cs;
+#pragma unroll
+    for (int m = 0; m < NK; ++m) {
+      const int k = wave + NW * m;
+      if (off[m] >= 0) dma16(g + off[m], buf + k * 256);
+    }
+  };
+  zero_lds(lds, 2 * BUF);
+  __syncthreads();
+  issue(0, lds);
+
+  // the 27 x 4 output gradients this lane combines, read once
+  float g[3][N][PX];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = 3 * wave + k;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (mode == 0) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy < H && gx < W) t = *reinterpret_cast<const float4*>(gb + (i * N + j) * cs + (long)gy * W + gx);
+        g[k][j][0] = t.x, g[k][j][1] = t.y, g[k][j][2] = t.z, g[k][j][3] = t.w;
+      } else {
+        const int yy = gy + i - D;
+        const float* gr = gb + (N * N - 1 - (i * N + j)) * cs + (long)yy * W;
+        const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          const int xx = gx + p + j - D;
+          g[k][j][p] = (rowok && xx >= 0 && xx < W) ? gr[xx] : 0.f;
+        }
+      }
+    }
+  }
+
+  const int nchunk = C / CC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    float* cur = lds + (ch & 1) * BUF;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk landed; previous chunk's partials have been consumed
+    if (ch + 1 < nchunk) issue((ch + 1) * CC, lds + ((ch + 1) & 1) * BUF);
+    const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
+#pragma unroll 1
+    for (int c = 0; c < CC; ++c) {
+      float pa[PX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float w[PX + 2 * D];
+        load_window(s2 + (c * SR + k) * SP, w);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+          for (int p = 0; p < PX; ++p) pa[p] = fmaf(g[k][j][p], w[j + p], pa[p]);
+      }
+      *reinterpret_cast<float4*>(part + ((wave * CC + c) * 64 + lane) * PX) =
+          make_float4(pa[0], pa[1], pa[2], pa[3]);
+    }
+    __syncthreads();
+    // sum the three waves' partials: CC*64 float4 results over 192 threads
+    for (int o = threadIdx.x; o < CC * 64; o += NT) {
+      const int c = o >> 6, l = o & 63;
+      int oxg, oy;
+      lane_xy(l, oxg, oy);
+      const float4 p0 = *reinterpret_cast<const float4*>(part + ((0 * CC + c) * 64 + l) * PX);
+      const float4 p1 = *reinterpret_cast<const float4*>(part + ((1 * CC + c) * 64 + l) * PX);
+      const float4 p2 = *reinterpret_cast<const float4*>(part + ((2 * CC + c) * 64 + l) * PX);
+      const int oyy = ty0 + oy, oxx = tx0 + 4 * oxg;
+      if (oyy < H && oxx < W)
+        *reinterpret_cast<float4*>(dstb + (long)(ch * CC + c) * cs + (long)oyy * W + oxx) =
+            make_float4((p0.x + p1.x + p2.x) * inv_c, (p0.y + p1.y + p2.y) * inv_c, (p0.z + p1.z + p2.z) * inv_c,
+                        (p0.w + p1.w + p2.w) * inv_c);
+    }
+  }
+}
+
+inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
+
+inline int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, hipStream_t st) {
+  dim3 grid(af_cdiv(W, TW), af_cdiv(H, TH), B);
+  hipLaunchKernelGGL(fwd_kernel, grid, dim3(NT), 0, st, x1, x2, out, C, H, W, 1.0f / (float)C);
+  return af_launch_status();
+}
+
+inline int launch_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2, int B, int C,
+                      int H, int W, hipStream_t st) {
+  const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
+  if (nmodes == 0) return ARFLOW_OK;
+  dim3 grid(af_cdiv(W, TW), af_cdiv(H, TH), B * nmodes);
+  hipLaunchKernelGGL(bwd_kernel, grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
+                     gx1 ? 0 : 1);
+  return af_launch_status();
+}
+
+}  // namespace corr_v2

@@ -83,8 +83,9 @@ __global__ __launch_bounds__(TX* TY) void census_fwd_kernel(const float* __restr
   if (mask) {
     af_block_sum<2>(part, red);
     if (threadIdx.x == 0) {
-      atomicAdd(sums, part[0]);
-      atomicAdd(sums + 1, part[1]);
+      float* slot = af_sum_slot(sums);
+      atomicAdd(slot, part[0]);
+      atomicAdd(slot + 1, part[1]);
     }
   }
 }
@@ -223,9 +224,10 @@ __global__ __launch_bounds__(TX* TY) void photo_fwd_kernel(const float* __restri
   }
   af_block_sum<3>(part, red);
   if (threadIdx.x == 0) {
-    atomicAdd(sums, part[0]);
-    atomicAdd(sums + 1, part[1]);
-    atomicAdd(sums + 2, part[2]);
+    float* slot = af_sum_slot(sums);
+    atomicAdd(slot, part[0]);
+    atomicAdd(slot + 1, part[1]);
+    atomicAdd(slot + 2, part[2]);
   }
 }
 
@@ -323,7 +325,7 @@ extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const flo
   if (mask) AF_REQUIRE_PTR(sums);
   hipStream_t st = (hipStream_t)stream;
   if (mask) {
-    hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
     if (e != hipSuccess) return af_hip_status(e);
   }
   dim3 grid(af_cdiv(W, TX), af_cdiv(H, TY), B);
@@ -360,7 +362,7 @@ extern "C" int arflow_photo_fwd(const float* im, const float* recons, const floa
   AF_REQUIRE_PTR(sums);
   AF_REQUIRE(B > 0 && C > 0 && H >= 3 && W >= 3 && B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, 3 * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
   if (e != hipSuccess) return af_hip_status(e);
   dim3 grid(af_cdiv(W, TX), af_cdiv(H, TY), B);
   hipLaunchKernelGGL(photo_fwd_kernel, grid, dim3(TX * TY), 0, st, im, recons, mask, ssim_map, sums, C, H, W);

@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __
   }
   af_block_sum<2>(part, red);
   if (threadIdx.x == 0) {
-    atomicAdd(sums, part[0]);
-    atomicAdd(sums + 1, part[1]);
+    float* slot = af_sum_slot(sums);
+    atomicAdd(slot, part[0]);
+    atomicAdd(slot + 1, part[1]);
   }
 }
 
@@ -171,7 +172,7 @@ extern "C" int arflow_smooth_fwd(const float* flow, const float* img, float* sum
   if (rc) return rc;
   AF_REQUIRE_PTR(sums);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
   if (e != hipSuccess) return af_hip_status(e);
   SmoothArgs a{flow, img, Ci, H, W, flow_bstride, flow_scale, alpha, order, wmode, penalty};
   hipLaunchKernelGGL(smooth_fwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, st, a, sums);

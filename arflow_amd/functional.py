@@ -63,6 +63,18 @@ def stop_kernel_timing():
     return out
 
 
+NSLOT, SLOT_STRIDE = 64, 32  # ARFLOW_NSLOT / ARFLOW_SLOT_STRIDE of include/arflow_hip.h
+
+
+def _new_sums(device):
+    return torch.empty(NSLOT * SLOT_STRIDE, device=device, dtype=torch.float32)
+
+
+def _fold_sums(buf, k):
+    """Slotted partial sums -> the k reduced quantities (one tiny reduction kernel)."""
+    return buf.view(NSLOT, SLOT_STRIDE)[:, :k].sum(0)
+
+
 def _call(name, *args, key=None):
     lib = _lib.load()
     if _timing is not None and key is not None:
@@ -199,11 +211,12 @@ class CensusLossFunction(torch.autograd.Function):
         if C != 3 or im_b.shape != im_a.shape or mask.shape != (B, 1, H, W):
             raise ValueError('census_loss expects [B,3,H,W] images and a [B,1,H,W] mask')
         r = int(patch_size) // 2
-        sums = torch.empty(2, device=im_a.device, dtype=torch.float32)
+        buf = _new_sums(im_a.device)
         dham = torch.empty(B, 1, H, W, device=im_a.device, dtype=torch.float32)
         with torch.cuda.device_of(im_a):
-            _call('arflow_census_fwd', _p(im_a), _p(im_b), _p(mask), None, _p(dham), _p(sums), B, H, W, r, _stream(),
+            _call('arflow_census_fwd', _p(im_a), _p(im_b), _p(mask), None, _p(dham), _p(buf), B, H, W, r, _stream(),
                   key=(B, H, W))
+        sums = _fold_sums(buf, 2)
         inv = 1.0 / (sums[1] + 1e-6)
         ctx.save_for_backward(im_a, im_b, dham, inv)
         ctx.r = r
@@ -272,12 +285,12 @@ class PhotoSumsFunction(torch.autograd.Function):
         im, recons = im.contiguous(), recons.contiguous()
         mask = None if mask is None else mask.contiguous()
         B, C, H, W = im.shape
-        sums = torch.empty(3, device=im.device, dtype=torch.float32)
+        buf = _new_sums(im.device)
         with torch.cuda.device_of(im):
-            _call('arflow_photo_fwd', _p(im), _p(recons), _p(mask), None, _p(sums), B, C, H, W, _stream(),
+            _call('arflow_photo_fwd', _p(im), _p(recons), _p(mask), None, _p(buf), B, C, H, W, _stream(),
                   key=(B, C, H, W))
         ctx.save_for_backward(im, recons, mask)
-        return sums
+        return _fold_sums(buf, 3)
 
     @staticmethod
     def backward(ctx, gsums):
@@ -300,7 +313,7 @@ class SSIMFunction(torch.autograd.Function):
         x, y = x.contiguous(), y.contiguous()
         B, C, H, W = x.shape
         out = torch.empty(B, C, H - 2, W - 2, device=x.device, dtype=torch.float32)
-        sums = torch.empty(3, device=x.device, dtype=torch.float32)
+        sums = _new_sums(x.device)
         with torch.cuda.device_of(x):
             # kernel convention: SSIM(recons*mask, im*mask) -> x plays "recons", y plays "im"
             _call('arflow_photo_fwd', _p(y), _p(x), None, _p(out), _p(sums), B, C, H, W, _stream())
@@ -338,13 +351,13 @@ class SmoothSumsFunction(torch.autograd.Function):
         Ci = img.shape[1]
         if img.shape[0] != B or img.shape[2:] != flow.shape[2:]:
             raise ValueError('smoothness: image and flow must share batch and spatial size')
-        sums = torch.empty(2, device=flow.device, dtype=torch.float32)
+        buf = _new_sums(flow.device)
         args = (B, Ci, H, W, fbs, float(flow_scale), float(alpha), int(order), int(wmode), int(penalty))
         with torch.cuda.device_of(flow):
-            _call('arflow_smooth_fwd', _p(flow), _p(img), _p(sums), *args, _stream(), key=(B, Ci, H, W))
+            _call('arflow_smooth_fwd', _p(flow), _p(img), _p(buf), *args, _stream(), key=(B, Ci, H, W))
         ctx.save_for_backward(flow, img)
         ctx.args = args
-        return sums
+        return _fold_sums(buf, 2)
 
     @staticmethod
     def backward(ctx, gsums):

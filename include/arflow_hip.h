@@ -52,6 +52,13 @@ typedef void* arflow_stream_t; /* hipStream_t */
 #define ARFLOW_COORDS_ABS 2     /* OR into `variant` / `mode` of splat_map / coord_mask: input holds
                                    absolute coordinates instead of a flow */
 
+/* Reduction outputs ("sums") are NOT single scalars: to avoid thousands of same-address atomics every
+ * workgroup adds its partial into one of ARFLOW_NSLOT rows, each on its own 128-byte line.
+ * A `sums` argument points to ARFLOW_NSLOT*ARFLOW_SLOT_STRIDE floats (zero-filled by the callee);
+ * quantity k is  sum_{s<NSLOT} sums[s*ARFLOW_SLOT_STRIDE + k]. */
+#define ARFLOW_NSLOT 64
+#define ARFLOW_SLOT_STRIDE 32
+
 int arflow_abi_version(void);
 const char* arflow_strerror(int code);
 
@@ -128,7 +135,7 @@ int arflow_census_bwd(const float* im_a, const float* im_b, const float* gham, c
  * sums[0] += sum |im-recons|*mask  (B*C*H*W terms)
  * sums[1] += sum dist              (B*C*(H-2)*(W-2) terms)
  * sums[2] += sum mask              (B*H*W terms)
- * ssim_map (nullable): [B,C,H-2,W-2].  mask nullable (= ones).  sums zero-filled here. */
+ * ssim_map (nullable): [B,C,H-2,W-2].  mask nullable (= ones).  sums: slotted, 3 quantities. */
 int arflow_photo_fwd(const float* im, const float* recons, const float* mask, float* ssim_map,
                      float* sums, int B, int C, int H, int W, arflow_stream_t stream);
 
@@ -146,7 +153,7 @@ int arflow_photo_bwd(const float* im, const float* recons, const float* mask, co
  *          losses/uflow_loss.py:81-102)
  * penalty 0: |v| (loss_blocks.py:101-103), 1: sqrt(v^2 + 1e-6) (penalty_uflow :8-9, robust_l1(v^2)
  * utils/uflow_utils.py:337-338).  flow: [B,2,H,W] (batch stride flow_bstride), flow values are
- * multiplied by flow_scale first; img: [B,Ci,H,W].  sums (2 floats) zero-filled here. */
+ * multiplied by flow_scale first; img: [B,Ci,H,W].  sums: slotted, 2 quantities. */
 int arflow_smooth_fwd(const float* flow, const float* img, float* sums, int B, int Ci, int H, int W,
                       long flow_bstride, float flow_scale, float alpha, int order, int wmode, int penalty,
                       arflow_stream_t stream);

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmark on the BASELINE shapes: HIP-event time per launch, algorithmic GB/s and
+fraction of the 8 TB/s HBM roofline.  Calls the C ABI directly (no autograd overhead).
+
+    python tools/kbench.py [--iters 50] [--filter corr] [--levels uflow|pwclite]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from arflow_amd import _lib  # noqa: E402
+from bench import algorithmic_bytes, HBM_PEAK_GBS  # noqa: E402
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def timeit(fn, iters):
+    st = torch.cuda.current_stream()
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--filter', default='')
+    ap.add_argument('--levels', default='uflow')
+    ap.add_argument('--batch', type=int, default=16, help='model-side batch (2B: both directions stacked)')
+    ap.add_argument('--size', type=int, nargs=2, default=[384, 640])
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    s = torch.cuda.current_stream().cuda_stream
+    H0, W0 = args.size
+    B2 = args.batch
+    if args.levels == 'uflow':
+        levels = [(32, H0 // 32, W0 // 32), (32, H0 // 16, W0 // 16), (32, H0 // 8, W0 // 8), (32, H0 // 4, W0 // 4)]
+    else:
+        levels = [(192, H0 // 64, W0 // 64), (128, H0 // 32, W0 // 32), (96, H0 // 16, W0 // 16),
+                  (64, H0 // 8, W0 // 8), (32, H0 // 4, W0 // 4)]
+    g = torch.Generator(device='cuda').manual_seed(0)
+    rows = []
+
+    def rec(name, shape, us):
+        nb = algorithmic_bytes(name, shape)
+        gbs = nb / us / 1e3
+        rows.append((name, shape, us, gbs))
+        print('%-22s %-26s %9.1f us %9.1f GB/s  %5.1f%% of HBM peak' % (name, list(shape), us, gbs, 100 * gbs / HBM_PEAK_GBS), flush=True)
+
+    def want(n):
+        return args.filter in n
+
+    for C, h, w in levels:
+        x1 = torch.randn(B2, C, h, w, device=dev, generator=g)
+        x2 = torch.randn(B2, C, h, w, device=dev, generator=g)
+        out = torch.empty(B2, 81, h, w, device=dev)
+        go = torch.randn(B2, 81, h, w, device=dev, generator=g)
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
+        fl = 2.0 * torch.randn(B2, 2, h, w, device=dev, generator=g)
+        wout = torch.empty_like(x1)
+        gfl = torch.empty_like(fl)
+        if want('corr_fwd'):
+            rec('arflow_corr_fwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_fwd(p(x1), p(x2), p(out), B2, C, h, w, 4, s), args.iters))
+        if want('corr_bwd'):
+            rec('arflow_corr_bwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_bwd(p(go), p(x1), p(x2), p(g1), p(g2), B2, C, h, w, 4, s), args.iters))
+        if want('warp_fwd'):
+            rec('arflow_warp_fwd', (B2, C, h, w), timeit(lambda: lib.arflow_warp_fwd(p(x2), p(fl), p(wout), None, B2, C, h, w, h, w, 2 * h * w, 0, 1, 0, s), args.iters))
+        if want('warp_bwd'):
+            rec('arflow_warp_bwd', (B2, C, h, w, True), timeit(lambda: lib.arflow_warp_bwd(p(x1), p(x2), p(fl), p(g2), p(gfl), B2, C, h, w, h, w, 2 * h * w, 0, 1, 0, s), args.iters))
+    # loss side: B = batch/2 image pairs at full resolution, per direction
+    B = max(1, B2 // 2)
+    im1 = torch.rand(B, 3, H0, W0, device=dev, generator=g)
+    im2 = torch.rand(B, 3, H0, W0, device=dev, generator=g)
+    mask = torch.ones(B, 1, H0, W0, device=dev)
+    fl0 = 2.0 * torch.randn(B, 2, H0, W0, device=dev, generator=g)
+    fl2 = 1.0 * torch.randn(B, 2, H0 // 4, W0 // 4, device=dev, generator=g)
+    rec3 = torch.empty_like(im1)
+    dham = torch.empty(B, 1, H0, W0, device=dev)
+    sums = torch.empty(64 * 32, device=dev)
+    gfl0 = torch.empty_like(fl0)
+    sm = torch.empty(B, 3, H0 // 4, W0 // 4, device=dev)
+    coef = torch.ones(2, device=dev)
+    gfl2 = torch.empty_like(fl2)
+    one = torch.ones(1, device=dev)
+    if want('warp_fwd'):
+        rec('arflow_warp_fwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_warp_fwd(p(im2), p(fl0), p(rec3), None, B, 3, H0, W0, H0, W0, 2 * H0 * W0, 0, 1, 1, s), args.iters))
+    if want('warp_bwd'):
+        rec('arflow_warp_bwd', (B, 3, H0, W0, False), timeit(lambda: lib.arflow_warp_bwd(p(im1), p(im2), p(fl0), None, p(gfl0), B, 3, H0, W0, H0, W0, 2 * H0 * W0, 0, 1, 1, s), args.iters))
+    if want('census_fwd'):
+        rec('arflow_census_fwd', (B, H0, W0), timeit(lambda: lib.arflow_census_fwd(p(im1), p(im2), p(mask), None, p(dham), p(sums), B, H0, W0, 3, s), args.iters))
+    if want('census_bwd'):
+        rec('arflow_census_bwd', (B, H0, W0), timeit(lambda: lib.arflow_census_bwd(p(im1), p(im2), p(dham), p(one), p(rec3), B, H0, W0, 3, s), args.iters))
+    if want('photo_fwd'):
+        rec('arflow_photo_fwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_photo_fwd(p(im1), p(im2), p(mask), None, p(sums), B, 3, H0, W0, s), args.iters))
+    if want('photo_bwd'):
+        rec('arflow_photo_bwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_photo_bwd(p(im1), p(im2), p(mask), None, p(coef), p(rec3), B, 3, H0, W0, s), args.iters))
+    if want('splat'):
+        rec('arflow_splat_map', (B, H0 // 4, W0 // 4), timeit(lambda: lib.arflow_splat_map(p(fl2), p(dham), B, H0 // 4, W0 // 4, 2 * (H0 // 4) * (W0 // 4), 0, s), args.iters))
+    if want('smooth_fwd'):
+        rec('arflow_smooth_fwd', (B, 3, H0 // 4, W0 // 4), timeit(lambda: lib.arflow_smooth_fwd(p(fl2), p(sm), p(sums), B, 3, H0 // 4, W0 // 4, 2 * (H0 // 4) * (W0 // 4), 1.0, 150.0, 1, 1, 1, s), args.iters))
+    if want('smooth_bwd'):
+        rec('arflow_smooth_bwd', (B, 3, H0 // 4, W0 // 4), timeit(lambda: lib.arflow_smooth_bwd(p(fl2), p(sm), p(coef), p(gfl2), B, 3, H0 // 4, W0 // 4, 2 * (H0 // 4) * (W0 // 4), 1.0, 150.0, 1, 1, 1, s), args.iters))
+    if want('down4'):
+        rec('arflow_down4', (B * 3, H0, W0), timeit(lambda: lib.arflow_down4(p(im1), p(sm), B * 3, H0, W0, s), args.iters))
+    if want('up4'):
+        rec('arflow_up4_clamp_mul', (B, H0 // 4, W0 // 4), timeit(lambda: lib.arflow_up4_clamp_mul(p(sm), p(mask), p(dham), B, H0 // 4, W0 // 4, s), args.iters))
+    tot_us = sum(r[2] for r in rows)
+    tot_b = sum(algorithmic_bytes(r[0], r[1]) for r in rows)
+    print(json.dumps({'kernels': len(rows), 'sum_us': tot_us, 'sum_GB': tot_b / 1e9, 'aggregate_GBps': tot_b / tot_us / 1e3,
+                      'aggregate_frac_of_hbm_peak': tot_b / tot_us / 1e3 / HBM_PEAK_GBS}))
+
+
+if __name__ == '__main__':
+    main()
