@@ -27,6 +27,8 @@ constexpr int SRC_FLOATS = CC * SR * SP;  // 2560 = 10 wave-wide DMA instruction
 constexpr int X1_FLOATS = CC * TH * SP;   // 1280 = 5  (32 of 40 floats used: pitch kept for banking)
 constexpr int SRC_DMA = SRC_FLOATS / 256, X1_DMA = X1_FLOATS / 256;
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void lane_xy(int lane, int& xg, int& y) {
   xg = ((lane >> 2) & 1) | (((lane >> 3) & 1) << 1) | ((lane & 1) << 2);
   y = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2);
@@ -56,23 +58,51 @@ __device__ __forceinline__ void zero_lds(float* lds, int nfloats) {
     *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// The empty asm pins each read as ONE ds_read_b128.  Left alone, hipcc re-splits the window into
+// ds_read2_b32 pairs (to feed v_pk_fma_f32 operands at odd offsets), which bank-conflict (32-bank
+// mode) and double the LDS instruction count: measured 57 % of LDS cycles lost in the backward kernel.
 __device__ __forceinline__ void load_window(const float* row, float (&w)[PX + 2 * D]) {
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    const float4 t = *reinterpret_cast<const float4*>(row + 4 * q);
+    f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * q);
+    asm volatile("" : "+v"(t));
     w[4 * q] = t.x, w[4 * q + 1] = t.y, w[4 * q + 2] = t.z, w[4 * q + 3] = t.w;
   }
 }
 
+__device__ __forceinline__ void load_vec4(const float* p, float (&v)[PX]) {
+  f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  asm volatile("" : "+v"(t));
+  v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+}
+
+// Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so
+// consecutive ids would put neighbouring tiles -- which share their 4-pixel halos -- on different L2s.
+// Give every XCD a contiguous run of tiles instead: id b runs tile (b % 8) * ceil(T/8) + b / 8.  Pure
+// speed: any placement is correct.  Returns false for the padding ids of the rounded-up grid.
+__device__ __forceinline__ bool tile_of_block(int ntx, int nty, int nimg, int& tx, int& ty, int& img) {
+  const int T = ntx * nty * nimg;
+  const int per = (T + 7) >> 3;
+  const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return false;
+  tx = t % ntx;
+  ty = (t / ntx) % nty;
+  img = t / (ntx * nty);
+  return true;
+}
+inline unsigned grid_for_tiles(int T) { return 8u * (unsigned)((T + 7) / 8); }
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                    float* __restrict__ out, int C, int H, int W, float inv_c) {
+                                                    float* __restrict__ out, int nimg, int C, int H, int W, float inv_c) {
   constexpr int BUF = SRC_FLOATS + X1_FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF + TH * SP];  // + pad: prefetch runs one channel ahead
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int xg, y;
   lane_xy(lane, xg, y);
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, b = blockIdx.z;
+  int btx, bty, b;
+  if (!tile_of_block((W + TW - 1) / TW, (H + TH - 1) / TH, nimg, btx, bty, b)) return;
+  const int tx0 = btx * TW, ty0 = bty * TH;
   const long cs = (long)H * W;
   const float* x1b = x1 + (long)b * C * cs;
   const float* x2b = x2 + (long)b * C * cs;
@@ -116,19 +146,35 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
     if (ch + 1 < nchunk) issue((ch + 1) * CC, lds + ((ch + 1) & 1) * BUF);
     const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
     const float* s1 = cur + SRC_FLOATS + y * SP + 4 * xg;
+    // software-pipelined over the 12 (channel, row-shift) steps: the window of the next step is
+    // requested before the 108 FMAs of the current one so the LDS latency hides behind them.  The
+    // prefetch past the last channel reads the next region of the LDS array (in bounds, unused).
+    float w[2][PX + 2 * D];
+    float a[PX], an[PX];
+    load_window(s2, w[0]);
+    load_vec4(s1, a);
 #pragma unroll 1
     for (int c = 0; c < CC; ++c) {
-      const float4 av = *reinterpret_cast<const float4*>(s1 + c * TH * SP);
-      const float a[PX] = {av.x, av.y, av.z, av.w};
+      const float* sc = s2 + c * SR * SP;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        float w[PX + 2 * D];
-        load_window(s2 + (c * SR + k) * SP, w);
+        // steps alternate buffers: step index t = 3c + k, parity = (c + k) & 1 handled by explicit swap
+        if (k < 2) {
+          load_window(sc + (k + 1) * SP, w[(k + 1) & 1]);
+        } else {
+          load_window(sc + SR * SP, w[(k + 1) & 1]);
+          load_vec4(s1 + (c + 1) * TH * SP, an);
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-          for (int p = 0; p < PX; ++p) acc[k][j][p] = fmaf(a[p], w[j + p], acc[k][j][p]);
+          for (int p = 0; p < PX; ++p) acc[k][j][p] = fmaf(a[p], w[k & 1][j + p], acc[k][j][p]);
       }
+      // after 3 steps the "next" window sits in w[1]; move it to w[0] for the next channel
+#pragma unroll
+      for (int q = 0; q < PX + 2 * D; ++q) w[0][q] = w[1][q];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) a[p] = an[p];
     }
   }
 
@@ -149,7 +195,7 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
 __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x1,
                                                     const float* __restrict__ x2, float* __restrict__ gx1,
                                                     float* __restrict__ gx2, int B, int C, int H, int W,
-                                                    float inv_c, int mode_base) {
+                                                    float inv_c, int mode_base, int nmodes) {
   constexpr int BUF = SRC_FLOATS;
   constexpr int PART = NW * CC * 64 * PX;  // 3072 floats
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF + PART];
@@ -157,9 +203,11 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int xg, y;
   lane_xy(lane, xg, y);
-  const int mode = mode_base + (int)(blockIdx.z / B);
-  const int b = blockIdx.z % B;
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  int btx, bty, img;
+  if (!tile_of_block((W + TW - 1) / TW, (H + TH - 1) / TH, B * nmodes, btx, bty, img)) return;
+  const int mode = mode_base + img / B;
+  const int b = img % B;
+  const int tx0 = btx * TW, ty0 = bty * TH;
   const long cs = (long)H * W;
   const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * cs;
   float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * cs;
@@ -216,20 +264,23 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
     __syncthreads();  // chunk landed; previous chunk's partials have been consumed
     if (ch + 1 < nchunk) issue((ch + 1) * CC, lds + ((ch + 1) & 1) * BUF);
     const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
+    float w[2][PX + 2 * D];
+    load_window(s2, w[0]);
 #pragma unroll 1
     for (int c = 0; c < CC; ++c) {
+      const float* sc = s2 + c * SR * SP;
       float pa[PX] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        float w[PX + 2 * D];
-        load_window(s2 + (c * SR + k) * SP, w);
+        load_window(k < 2 ? sc + (k + 1) * SP : sc + SR * SP, w[(k + 1) & 1]);  // next step (in-bounds past the end)
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-          for (int p = 0; p < PX; ++p) pa[p] = fmaf(g[k][j][p], w[j + p], pa[p]);
+          for (int p = 0; p < PX; ++p) pa[p] = fmaf(g[k][j][p], w[k & 1][j + p], pa[p]);
       }
-      *reinterpret_cast<float4*>(part + ((wave * CC + c) * 64 + lane) * PX) =
-          make_float4(pa[0], pa[1], pa[2], pa[3]);
+#pragma unroll
+      for (int q = 0; q < PX + 2 * D; ++q) w[0][q] = w[1][q];
+      *reinterpret_cast<float4*>(part + ((wave * CC + c) * 64 + lane) * PX) = make_float4(pa[0], pa[1], pa[2], pa[3]);
     }
     __syncthreads();
     // sum the three waves' partials: CC*64 float4 results over 192 threads
@@ -252,8 +303,8 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
 
 inline int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, hipStream_t st) {
-  dim3 grid(af_cdiv(W, TW), af_cdiv(H, TH), B);
-  hipLaunchKernelGGL(fwd_kernel, grid, dim3(NT), 0, st, x1, x2, out, C, H, W, 1.0f / (float)C);
+  dim3 grid(grid_for_tiles(af_cdiv(W, TW) * af_cdiv(H, TH) * B));
+  hipLaunchKernelGGL(fwd_kernel, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C);
   return af_launch_status();
 }
 
@@ -261,9 +312,9 @@ inline int launch_bwd(const float* gout, const float* x1, const float* x2, float
                       int H, int W, hipStream_t st) {
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
-  dim3 grid(af_cdiv(W, TW), af_cdiv(H, TH), B * nmodes);
+  dim3 grid(grid_for_tiles(af_cdiv(W, TW) * af_cdiv(H, TH) * B * nmodes));
   hipLaunchKernelGGL(bwd_kernel, grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
-                     gx1 ? 0 : 1);
+                     gx1 ? 0 : 1, nmodes);
   return af_launch_status();
 }
 
