@@ -4,17 +4,19 @@
 // One workgroup = 3 waves over one 8 x 32 pixel tile.  Wave w owns the row shifts i = 3w..3w+2; a
 // lane owns 4 consecutive pixels of one tile row.
 //   * staging: the operand tile (+4 px halo: 16 rows x 40 floats) of 4 channels is brought in by
-//     LDS-DMA (global_load_lds_dwordx4: per-lane global address, linear LDS destination) into a
-//     double buffer, issued one chunk ahead of the FMAs -- no staging VGPRs, one barrier per chunk.
-//     The halo outside the image is never written: LDS is zero-filled once and out-of-image lanes are
-//     masked off for every chunk (the pattern depends on the tile only).
+//     LDS-DMA (global_load_lds_dwordx4: per-lane global address, linear LDS destination) into a ring
+//     of NBUF buffers, issued NBUF-1 chunks ahead of the FMAs -- no staging VGPRs, one barrier per
+//     chunk, counted s_waitcnt vmcnt(N) so younger chunks stay in flight across the barrier.
+//     Pieces outside the image are sourced from a 16-byte block of zeros in device memory, so every
+//     lane of every DMA instruction is active (exact instruction counts, no LDS pre-fill).
 //   * the lane -> (pixel group, row) map is a bit permutation chosen so that every ds_read_b128 of a
 //     12-float window row is bank-conflict free with the native 40-float pitch (searched offline
-//     against the gfx950 b128 lane groups).
+//     against the gfx950 b128 lane groups); SQ_LDS_BANK_CONFLICT = 0 measured.
 //   * forward: 3 x 9 x 4 accumulators per lane; per channel 1 + 9 b128 LDS reads feed 108 FMAs.
 //   * backward: the lane keeps its 3 x 9 x 4 output gradients in VGPRs for the whole kernel (gout is
 //     read once); per channel it produces a 4-pixel partial sum over its 27 displacements, the three
 //     waves' partials meet in LDS and are summed + stored by the workgroup.
+//   * workgroup -> tile order is XCD-aware (tiles sharing halos share an L2).
 #pragma once
 #include "common.hpp"
 
@@ -29,6 +31,9 @@ constexpr int SRC_DMA = SRC_FLOATS / 256, X1_DMA = X1_FLOATS / 256;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 16 zero bytes in device memory: DMA source of every piece outside the image.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ void lane_xy(int lane, int& xg, int& y) {
   xg = ((lane >> 2) & 1) | (((lane >> 3) & 1) << 1) | ((lane & 1) << 2);
   y = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 1) & 1) << 2);
@@ -39,9 +44,9 @@ __device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Descriptor of the 16-byte piece this lane moves in wave-wide DMA instruction `k` of a staged
-// region with `rows` rows per channel: element offset inside the [C,H,W] image (relative to channel
-// c0) or -1 when the piece lies outside the image / in the pad columns.
+// Element offset (inside one [C,H,W] image, relative to channel c0) of the 16-byte piece this lane
+// moves in wave-wide DMA instruction `k` of a staged region with `rows` rows per channel, or -1 when
+// the piece lies outside the image / in the pad columns.
 __device__ __forceinline__ int piece_offset(int k, int lane, int rows, int used_slots, int gy0, int gx0,
                                             int H, int W) {
   const int s = k * 64 + lane;
@@ -53,9 +58,13 @@ __device__ __forceinline__ int piece_offset(int k, int lane, int rows, int used_
   return (c * H + gy) * W + gx;
 }
 
-__device__ __forceinline__ void zero_lds(float* lds, int nfloats) {
-  for (int i = threadIdx.x * 4; i < nfloats; i += NT * 4)
-    *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+// wait until at most N_OUT of this wave's vector-memory operations are outstanding, then barrier.
+// Raw s_barrier: __syncthreads() would drain every in-flight DMA (vmcnt(0)).
+template <int N_OUT>
+__device__ __forceinline__ void wait_dma_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_OUT) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 // The empty asm pins each read as ONE ds_read_b128.  Left alone, hipcc re-splits the window into
@@ -69,7 +78,6 @@ __device__ __forceinline__ void load_window(const float* row, float (&w)[PX + 2 
     w[4 * q] = t.x, w[4 * q + 1] = t.y, w[4 * q + 2] = t.z, w[4 * q + 3] = t.w;
   }
 }
-
 __device__ __forceinline__ void load_vec4(const float* p, float (&v)[PX]) {
   f32x4 t = *reinterpret_cast<const f32x4*>(p);
   asm volatile("" : "+v"(t));
@@ -93,10 +101,12 @@ __device__ __forceinline__ bool tile_of_block(int ntx, int nty, int nimg, int& t
 inline unsigned grid_for_tiles(int T) { return 8u * (unsigned)((T + 7) / 8); }
 
 // ------------------------------------------------------------------------------------------------
+template <int NBUF>
 __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                    float* __restrict__ out, int nimg, int C, int H, int W, float inv_c) {
+                                                    float* __restrict__ out, int nimg, int C, int H, int W,
+                                                    float inv_c) {
   constexpr int BUF = SRC_FLOATS + X1_FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF + TH * SP];  // + pad: prefetch runs one channel ahead
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + TH * SP];  // + pad: prefetch runs a channel ahead
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int xg, y;
   lane_xy(lane, xg, y);
@@ -116,19 +126,20 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
     off[m] = k < SRC_DMA ? piece_offset(k, lane, SR, SP / 4, ty0 - D, tx0 - D, H, W)
                          : piece_offset(k - SRC_DMA, lane, TH, TW / 4, ty0, tx0, H, W);
   }
-  auto issue = [&](int c0, float* buf) {
+  auto issue = [&](int chunk) {
+    float* buf = lds + (chunk % NBUF) * BUF;
 #pragma unroll
     for (int m = 0; m < NK; ++m) {
       const int k = wave + NW * m;
-      const float* g = (k < SRC_DMA ? x2b : x1b) + (long)c0 * cs;
-      float* dst = buf + k * 256;  // x1 region follows the x2 region: block index k carries over
-      if (off[m] >= 0) dma16(g + off[m], dst);
+      const float* g = (k < SRC_DMA ? x2b : x1b) + (long)chunk * CC * cs;
+      dma16(off[m] >= 0 ? g + off[m] : g_zero16, buf + k * 256);  // x1 region follows x2: block k carries over
     }
   };
 
-  zero_lds(lds, 2 * BUF);
-  __syncthreads();
-  issue(0, lds);
+  const int nchunk = C / CC;
+#pragma unroll
+  for (int pre = 0; pre < NBUF - 1; ++pre)
+    if (pre < nchunk) issue(pre);
 
   float acc[3][N][PX];
 #pragma unroll
@@ -138,12 +149,15 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
 #pragma unroll
       for (int p = 0; p < PX; ++p) acc[k][j][p] = 0.f;
 
-  const int nchunk = C / CC;
   for (int ch = 0; ch < nchunk; ++ch) {
-    float* cur = lds + (ch & 1) * BUF;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // chunk `ch` has landed for every wave; buffer (ch+1)&1 is no longer being read
-    if (ch + 1 < nchunk) issue((ch + 1) * CC, lds + ((ch + 1) & 1) * BUF);
+    // chunk ch must have landed; the NBUF-2 younger chunks may stay in flight
+    if (ch + NBUF - 2 < nchunk)
+      wait_dma_and_barrier<(NBUF - 2) * NK>();
+    else
+      wait_dma_and_barrier<0>();
+    // every wave is past the FMAs of chunk ch-1, whose buffer the next DMA overwrites
+    if (ch + NBUF - 1 < nchunk) issue(ch + NBUF - 1);
+    const float* cur = lds + (ch % NBUF) * BUF;
     const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
     const float* s1 = cur + SRC_FLOATS + y * SP + 4 * xg;
     // software-pipelined over the 12 (channel, row-shift) steps: the window of the next step is
@@ -158,7 +172,6 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
       const float* sc = s2 + c * SR * SP;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        // steps alternate buffers: step index t = 3c + k, parity = (c + k) & 1 handled by explicit swap
         if (k < 2) {
           load_window(sc + (k + 1) * SP, w[(k + 1) & 1]);
         } else {
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
 #pragma unroll
           for (int p = 0; p < PX; ++p) acc[k][j][p] = fmaf(a[p], w[k & 1][j + p], acc[k][j][p]);
       }
-      // after 3 steps the "next" window sits in w[1]; move it to w[0] for the next channel
+      // after 3 steps the "next" window sits in w[1]; it becomes w[0] of the next channel
 #pragma unroll
       for (int q = 0; q < PX + 2 * D; ++q) w[0][q] = w[1][q];
 #pragma unroll
@@ -192,14 +205,15 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
 // ------------------------------------------------------------------------------------------------
 // mode 0: gx1[c,p] = (1/C) sum_{i,j} g[i*9+j][p]        * x2[c][p+(i-4,j-4)]
 // mode 1: gx2[c,q] = (1/C) sum_{i,j} g[80-(i*9+j)][q+(i-4,j-4)] * x1[c][q+(i-4,j-4)]
+template <int NBUF>
 __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x1,
                                                     const float* __restrict__ x2, float* __restrict__ gx1,
                                                     float* __restrict__ gx2, int B, int C, int H, int W,
                                                     float inv_c, int mode_base, int nmodes) {
   constexpr int BUF = SRC_FLOATS;
   constexpr int PART = NW * CC * 64 * PX;  // 3072 floats
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF + PART];
-  float* part = lds + 2 * BUF;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + PART];
+  float* part = lds + NBUF * BUF;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int xg, y;
   lane_xy(lane, xg, y);
@@ -214,24 +228,27 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   const float* gb = gout + (long)b * N * N * cs;
   const int gy = ty0 + y, gx = tx0 + 4 * xg;
 
-  constexpr int NK = (SRC_DMA + NW - 1) / NW;  // 4 (wave 0) / 3
-  int off[NK];
+  // 10 DMA instructions per chunk over 3 waves: every wave issues 4 (the surplus two re-send piece 9,
+  // identical bytes to the same LDS block) so that the per-wave count is a compile-time constant
+  constexpr int NK = (SRC_DMA + NW - 1) / NW;  // 4
+  int off[NK], blk[NK];
 #pragma unroll
   for (int m = 0; m < NK; ++m) {
-    const int k = wave + NW * m;
-    off[m] = k < SRC_DMA ? piece_offset(k, lane, SR, SP / 4, ty0 - D, tx0 - D, H, W) : -1;
+    int k = wave + NW * m;
+    if (k >= SRC_DMA) k = SRC_DMA - 1;
+    blk[m] = k;
+    off[m] = piece_offset(k, lane, SR, SP / 4, ty0 - D, tx0 - D, H, W);
   }
-  auto issue = [&](int c0, float* buf) {
-    const float* g = srcb + (long)c0 * cs;
+  auto issue = [&](int chunk) {
+    float* buf = lds + (chunk % NBUF) * BUF;
+    const float* g = srcb + (long)chunk * CC * cs;
 #pragma unroll
-    for (int m = 0; m < NK; ++m) {
-      const int k = wave + NW * m;
-      if (off[m] >= 0) dma16(g + off[m], buf + k * 256);
-    }
+    for (int m = 0; m < NK; ++m) dma16(off[m] >= 0 ? g + off[m] : g_zero16, buf + blk[m] * 256);
   };
-  zero_lds(lds, 2 * BUF);
-  __syncthreads();
-  issue(0, lds);
+  const int nchunk = C / CC;
+#pragma unroll
+  for (int pre = 0; pre < NBUF - 1; ++pre)
+    if (pre < nchunk) issue(pre);
 
   // the 27 x 4 output gradients this lane combines, read once
   float g[3][N][PX];
@@ -256,13 +273,19 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
       }
     }
   }
+  // the g loads above are younger than the prologue DMA: drain everything once, then count exactly
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  const int nchunk = C / CC;
   for (int ch = 0; ch < nchunk; ++ch) {
-    float* cur = lds + (ch & 1) * BUF;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // chunk landed; previous chunk's partials have been consumed
-    if (ch + 1 < nchunk) issue((ch + 1) * CC, lds + ((ch + 1) & 1) * BUF);
+    // chunk ch landed (stores of the previous reduce may still drain: they are older than the DMA of
+    // chunk ch+NBUF-2 only when NBUF == 2, so count conservatively: wait for everything but the
+    // youngest (NBUF-2)*NK DMA instructions)
+    if (ch + NBUF - 2 < nchunk && ch > 0)
+      wait_dma_and_barrier<(NBUF - 2) * NK>();
+    else
+      wait_dma_and_barrier<0>();
+    if (ch + NBUF - 1 < nchunk) issue(ch + NBUF - 1);
+    const float* cur = lds + (ch % NBUF) * BUF;
     const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
     float w[2][PX + 2 * D];
     load_window(s2, w[0]);
@@ -282,7 +305,9 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
       for (int q = 0; q < PX + 2 * D; ++q) w[0][q] = w[1][q];
       *reinterpret_cast<float4*>(part + ((wave * CC + c) * 64 + lane) * PX) = make_float4(pa[0], pa[1], pa[2], pa[3]);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     // sum the three waves' partials: CC*64 float4 results over 192 threads
     for (int o = threadIdx.x; o < CC * 64; o += NT) {
       const int c = o >> 6, l = o & 63;
@@ -303,8 +328,14 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
 
 inline int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, hipStream_t st) {
-  dim3 grid(grid_for_tiles(af_cdiv(W, TW) * af_cdiv(H, TH) * B));
-  hipLaunchKernelGGL(fwd_kernel, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C);
+  const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B;
+  dim3 grid(grid_for_tiles(tiles));
+  // many tiles: 4 workgroups per CU hide each other's DMA latency, keep LDS small (2 buffers);
+  // few tiles: one workgroup per CU -> deeper ring so its own DMA runs 3 chunks ahead
+  if (tiles >= 768)
+    hipLaunchKernelGGL(fwd_kernel<2>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C);
+  else
+    hipLaunchKernelGGL(fwd_kernel<4>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C);
   return af_launch_status();
 }
 
@@ -312,9 +343,14 @@ inline int launch_bwd(const float* gout, const float* x1, const float* x2, float
                       int H, int W, hipStream_t st) {
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
-  dim3 grid(grid_for_tiles(af_cdiv(W, TW) * af_cdiv(H, TH) * B * nmodes));
-  hipLaunchKernelGGL(bwd_kernel, grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
-                     gx1 ? 0 : 1, nmodes);
+  const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B * nmodes;
+  dim3 grid(grid_for_tiles(tiles));
+  if (tiles >= 768)
+    hipLaunchKernelGGL(bwd_kernel<2>, grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
+                       gx1 ? 0 : 1, nmodes);
+  else
+    hipLaunchKernelGGL(bwd_kernel<4>, grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
+                       gx1 ? 0 : 1, nmodes);
   return af_launch_status();
 }
 
