@@ -92,7 +92,9 @@ def cpu_baseline(workload, height, width, budget_s=25.0):
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     B = 1
     x = synthetic_pairs(B, height, width, device='cpu')
-    cores = torch.get_num_threads()
+    # the GPU box gives one GPU a 16-core CPU share: more torch threads than that only oversubscribe
+    cores = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
     times = []
     with oracle_ops(model):
         t_start = time.time()
@@ -125,6 +127,8 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='image pairs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations for MIOpen')
+    ap.add_argument('--miopen-benchmark', action='store_true', help='experiment: exhaustive MIOpen find')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -147,7 +151,9 @@ def main():
     from arflow_amd.train_step import TrainStep, synthetic_pairs
 
     H, W = args.size
-    step = TrainStep(args.workload, device, seed=1234)
+    if args.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
+    step = TrainStep(args.workload, device, seed=1234, channels_last=args.channels_last)
     torch.manual_seed(1000 + rank)  # level-dropout draws differ per rank, like independent workers
     img = synthetic_pairs(args.batch, H, W, device=device, seed=100 + rank)
 

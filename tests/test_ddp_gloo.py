@@ -1,0 +1,133 @@
+"""CPU, world_size 2 over gloo: the flat-bucket gradient all-reduce (arflow_amd/ddp.py) that bench.py
+uses with RCCL on the GPUs.  Checks that (1) every rank ends with the mean of the per-rank gradients,
+bucket by bucket, including parameters that received no gradient, (2) replicas stay bit-identical after
+optimizer steps, (3) sharding the image-pair batch over ranks reproduces the single-process gradient of
+the host model (oracle ops patched in: no GPU here)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker_basic(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from arflow_amd.ddp import FlatGradAllReduce
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8), torch.nn.Tanh(),
+                              torch.nn.Linear(8, 3))
+    unused = torch.nn.Linear(4, 4)  # never touched by forward: its bucket must still be reduced
+    net.add_module('unused', unused)
+    import copy
+    red = FlatGradAllReduce(net, n_buckets=3)
+    red.broadcast_parameters(0)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(100 + rank)
+
+    def fwd(m, x):
+        return m[4](m[3](m[2](m[1](m[0](x))))).square().mean()
+
+    for step in range(3):
+        x = torch.randn(5, 6, generator=g)
+        # this rank's own gradient, from a hook-free twin (the hooks reduce red.flat in place, asynchronously)
+        twin = copy.deepcopy(net)
+        ps = list(twin.parameters())
+        gs = torch.autograd.grad(fwd(twin, x), ps, allow_unused=True)
+        local = torch.cat([(gi if gi is not None else torch.zeros_like(p)).flatten() for gi, p in zip(reversed(gs), reversed(ps))])
+        red.zero_grad()
+        fwd(net, x).backward()
+        red.finish()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(red.flat, sum(gathered) / world, atol=1e-7), 'flat buffer is not the mean'
+        assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in net.parameters())
+        opt.step()
+    flat_params = torch.cat([p.detach().flatten() for p in net.parameters()])
+    others = [torch.zeros_like(flat_params) for _ in range(world)]
+    dist.all_gather(others, flat_params)
+    assert torch.equal(others[0], others[1]), 'replicas diverged'
+    q.put((rank, len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def _worker_model(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from arflow_amd.config import AttrDict
+    from arflow_amd.ddp import FlatGradAllReduce
+    from arflow_amd.models import PWCLite
+    from oracle import losses as OL
+    from oracle.fixture_common import fill_deterministic
+    from oracle.host_models import oracle_ops
+    model = fill_deterministic(PWCLite(AttrDict(upsample=True, n_frames=2, reduce_dense=True))).train()
+    red = FlatGradAllReduce(model, n_buckets=4)
+    cfg = AttrDict(w_l1=1.0, w_ssim=0.0, w_ternary=0.0, warp_pad='border', alpha=10, occ_from_back=True, with_bk=True,
+                   w_smooth=10.0, w_scales=[1.0, 1.0, 1.0, 1.0, 1.0, 0.0], w_sm_scales=[1.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    loss = OL.unFlowLoss(cfg)
+    g = torch.Generator().manual_seed(7)
+    full = torch.rand(2, 6, 64, 64, generator=g)
+
+    def run(m, batch):
+        with oracle_ops(m):
+            res = m(batch, with_bk=True)
+            flows = [torch.cat([a, b], 1) for a, b in zip(res['flows_fw'], res['flows_bw'])]
+            return loss(flows, batch)[0]
+
+    red.zero_grad()
+    run(model, full[rank:rank + 1]).backward()  # hooks launch the bucket all-reduces
+    red.finish()
+    sharded = red.flat.clone()
+    if rank == 0:
+        # single-process reference on a hook-free replica: mean of the two per-sample gradients
+        ref_model = fill_deterministic(PWCLite(AttrDict(upsample=True, n_frames=2, reduce_dense=True))).train()
+        params = [p for p in ref_model.parameters()]
+        tot = None
+        for i in range(2):
+            gs = torch.autograd.grad(run(ref_model, full[i:i + 1]), params, allow_unused=True)
+            gs = [g if g is not None else torch.zeros_like(p) for g, p in zip(gs, params)]
+            tot = gs if tot is None else [a + b for a, b in zip(tot, gs)]
+        ref = torch.cat([g.flatten() for g in reversed(tot)]) / 2  # the flat buffer is in reverse registration order
+        err = float((sharded - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        q.put(('model', err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(worker, n=2):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, n, port, q)) for r in range(n)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, 'rank failed'
+    out = []
+    while not q.empty():
+        out.append(q.get())
+    return out
+
+
+def test_flat_bucket_allreduce_world2():
+    out = _run(_worker_basic)
+    assert sorted(r for r, _ in out) == [0, 1]
+    assert all(2 <= nb <= 3 for _, nb in out)
+
+
+def test_batch_sharding_reproduces_single_process_gradient():
+    out = _run(_worker_model)
+    assert out and out[0][0] == 'model'
+    assert out[0][1] < 1e-5, 'sharded gradient differs from the single-process one: rel err %g' % out[0][1]
