@@ -262,14 +262,29 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
         if (gy < H && gx < W) t = *reinterpret_cast<const float4*>(gb + (i * N + j) * cs + (long)gy * W + gx);
         g[k][j][0] = t.x, g[k][j][1] = t.y, g[k][j][2] = t.z, g[k][j][3] = t.w;
       } else {
+        // 4 consecutive pixels starting at gx + (j-4): one or two ALIGNED float4 loads (gx and W are
+        // multiples of 4, so an aligned block is entirely inside or outside a row) + a compile-time
+        // register shift, instead of 4 bounds-checked scalar loads
         const int yy = gy + i - D;
         const float* gr = gb + (N * N - 1 - (i * N + j)) * cs + (long)yy * W;
         const bool rowok = yy >= 0 && yy < H;
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-          const int xx = gx + p + j - D;
-          g[k][j][p] = (rowok && xx >= 0 && xx < W) ? gr[xx] : 0.f;
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int e = j - D;                       // -4 .. 4 (compile-time after unrolling)
+        const int blo = (e >= 0 ? e / 4 : -((3 - e) / 4)) * 4;  // 4*floor(e/4)
+        const int sh = e - blo;                    // 0..3
+        float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+        const int xlo = gx + blo, xhi = xlo + 4;
+        if (rowok && xlo >= 0 && xlo < W) {
+          const float4 t = *reinterpret_cast<const float4*>(gr + xlo);
+          lo[0] = t.x, lo[1] = t.y, lo[2] = t.z, lo[3] = t.w;
         }
+        if (sh != 0 && rowok && xhi >= 0 && xhi < W) {
+          const float4 t = *reinterpret_cast<const float4*>(gr + xhi);
+          hi[0] = t.x, hi[1] = t.y, hi[2] = t.z, hi[3] = t.w;
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) g[k][j][p] = (p + sh < 4) ? lo[p + sh] : hi[p + sh - 4];
       }
     }
   }

@@ -43,6 +43,24 @@ __device__ __forceinline__ Taps make_taps(float px, float py, float u, float v, 
   return t;
 }
 
+// Branch-free channel loop: the four tap addresses are clamped into the source once (always
+// dereferenceable) and taps outside the image are selected to zero after the load, so all loads of
+// several unrolled channels are in flight together (the per-tap `if` form serialised them).
+struct TapPlan {
+  int o[4];     // element offsets inside one source plane (clamped)
+  float w[4];   // bilinear weights
+  bool ok[4];   // tap inside the source
+};
+__device__ __forceinline__ TapPlan plan_taps(const Taps& t, int Hs, int Ws) {
+  TapPlan p;
+  const int xa = min(max(t.x0, 0), Ws - 1), xb = min(max(t.x0 + 1, 0), Ws - 1);
+  const int ya = min(max(t.y0, 0), Hs - 1), yb = min(max(t.y0 + 1, 0), Hs - 1);
+  p.o[0] = ya * Ws + xa, p.o[1] = ya * Ws + xb, p.o[2] = yb * Ws + xa, p.o[3] = yb * Ws + xb;
+  p.w[0] = t.wx0 * t.wy0, p.w[1] = t.wx1 * t.wy0, p.w[2] = t.wx0 * t.wy1, p.w[3] = t.wx1 * t.wy1;
+  p.ok[0] = t.vx0 && t.vy0, p.ok[1] = t.vx1 && t.vy0, p.ok[2] = t.vx0 && t.vy1, p.ok[3] = t.vx1 && t.vy1;
+  return p;
+}
+
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ src,
                                                        const float* __restrict__ flow,
                                                        float* __restrict__ out, float* __restrict__ valid,
@@ -60,21 +78,19 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     valid[((long)b * H + y) * W + x] =
         (cx >= 0.f && cx <= (float)(W - 1) && cy >= 0.f && cy <= (float)(H - 1)) ? 1.f : 0.f;
   }
-  const float wnw = t.wx0 * t.wy0, wne = t.wx1 * t.wy0, wsw = t.wx0 * t.wy1, wse = t.wx1 * t.wy1;
-  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
-  const long o00 = (long)t.y0 * Ws + t.x0;
-  const long ss = (long)Hs * Ws, os = (long)H * W;
+  const TapPlan p = plan_taps(t, Hs, Ws);
+  const int ss = Hs * Ws, os = H * W;
   const float* sp = src + (long)b * C * ss;
   float* op = out + (long)b * C * os + (long)y * W + x;
-#pragma unroll 4
+#pragma unroll 8
   for (int c = 0; c < C; ++c) {
-    const float* s = sp + c * ss + o00;
-    float r = 0.f;
-    if (bnw) r = s[0] * wnw;
-    if (bne) r = fmaf(s[1], wne, r);
-    if (bsw) r = fmaf(s[Ws], wsw, r);
-    if (bse) r = fmaf(s[Ws + 1], wse, r);
-    op[c * os] = r;
+    const float* s = sp + (long)c * ss;
+    const float a0 = s[p.o[0]], a1 = s[p.o[1]], a2 = s[p.o[2]], a3 = s[p.o[3]];
+    float r = p.ok[0] ? a0 * p.w[0] : 0.f;
+    r = p.ok[1] ? fmaf(a1, p.w[1], r) : r;
+    r = p.ok[2] ? fmaf(a2, p.w[2], r) : r;
+    r = p.ok[3] ? fmaf(a3, p.w[3], r) : r;
+    op[(long)c * os] = r;
   }
 }
 
@@ -99,7 +115,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   float* gp = WITH_SRC ? gsrc + (long)b * C * ss : nullptr;
   const float* gop = gout + (long)b * C * os + (long)y * W + x;
   float gix = 0.f, giy = 0.f;
-#pragma unroll 2
+  const TapPlan tp = plan_taps(t, Hs, Ws);
+#pragma unroll 4
   for (int c = 0; c < C; ++c) {
     const float g = gop[c * os];
     if (WITH_SRC) {
@@ -110,9 +127,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
       if (bse) atomicAdd(d + Ws + 1, g * wse);
     }
     if (WITH_FLOW) {
-      const float* s = sp + c * ss + o00;
-      const float nw = bnw ? s[0] : 0.f, ne = bne ? s[1] : 0.f;
-      const float sw = bsw ? s[Ws] : 0.f, se = bse ? s[Ws + 1] : 0.f;
+      const float* s = sp + c * ss;
+      const float a0 = s[tp.o[0]], a1 = s[tp.o[1]], a2 = s[tp.o[2]], a3 = s[tp.o[3]];
+      const float nw = bnw ? a0 : 0.f, ne = bne ? a1 : 0.f;
+      const float sw = bsw ? a2 : 0.f, se = bse ? a3 : 0.f;
       // d out / d ix = (ne-nw)*wy0 + (se-sw)*wy1 ; d out / d iy = (sw-nw)*wx0 + (se-ne)*wx1
       gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
       giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
@@ -206,10 +224,12 @@ __global__ __launch_bounds__(NT) void warp_bwd_lds_kernel(const float* __restric
   const float* gop = gout + (long)b * C * os + (long)y * W + x;
   float gix = 0.f, giy = 0.f;
 
+  const TapPlan tp = plan_taps(t, Hs, Ws);
   auto flow_terms = [&](int c, float g) {
-    const float* s = sp + c * ss + o00;
-    const float nw = ok[0] ? s[0] : 0.f, ne = ok[1] ? s[1] : 0.f;
-    const float sw = ok[2] ? s[Ws] : 0.f, se = ok[3] ? s[Ws + 1] : 0.f;
+    const float* s = sp + c * ss;
+    const float a0 = s[tp.o[0]], a1 = s[tp.o[1]], a2 = s[tp.o[2]], a3 = s[tp.o[3]];
+    const float nw = ok[0] ? a0 : 0.f, ne = ok[1] ? a1 : 0.f;
+    const float sw = ok[2] ? a2 : 0.f, se = ok[3] ? a3 : 0.f;
     gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
     giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
   };
