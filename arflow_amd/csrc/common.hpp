@@ -55,10 +55,27 @@ __device__ __forceinline__ void af_block_sum(float (&v)[NV], float* scratch) {
 
 // Row of the slotted `sums` buffer this workgroup adds into (see ARFLOW_NSLOT in the header).
 __device__ __forceinline__ float* af_sum_slot(float* sums) {
-  const unsigned s = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) % ARFLOW_NSLOT;
+  const unsigned s = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z + (blockIdx.x >> 6)) % ARFLOW_NSLOT;
   return sums + s * ARFLOW_SLOT_STRIDE;
 }
 #define AF_SUMS_BYTES (sizeof(float) * ARFLOW_NSLOT * ARFLOW_SLOT_STRIDE)
+
+// XCD-aware workgroup -> tile map for 1-D grids of 2-D tiles.  Workgroups are dealt round-robin over the
+// 8 XCDs (private L2 each), so consecutive ids would spread neighbouring tiles -- which share halo rows
+// and bilinear taps -- over different L2s (measured: 2.6x fabric read over-fetch in the warp forward).
+// Give every XCD a contiguous run of tiles: id b runs tile (b % 8) * ceil(T/8) + b / 8.  Pure speed.
+// Returns false for the padding ids of the rounded-up grid (launch with af_grid_for_tiles(T) blocks).
+__device__ __forceinline__ bool af_tile_of_block(int ntx, int nty, int nimg, int& tx, int& ty, int& img) {
+  const int T = ntx * nty * nimg;
+  const int per = (T + 7) >> 3;
+  const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return false;
+  tx = t % ntx;
+  ty = (t / ntx) % nty;
+  img = t / (ntx * nty);
+  return true;
+}
+static inline unsigned af_grid_for_tiles(long T) { return 8u * (unsigned)((T + 7) / 8); }
 
 // torch grid_sample un-normalisation (ATen/native/GridSampler.h:27-36).
 __device__ __forceinline__ float af_unnormalize(float g, int size, bool align) {

@@ -42,11 +42,13 @@ __global__ __launch_bounds__(TX* TY) void census_fwd_kernel(const float* __restr
                                                             const float* __restrict__ mask,
                                                             float* __restrict__ ham_out,
                                                             float* __restrict__ dham_out,
-                                                            float* __restrict__ sums, int H, int W) {
+                                                            float* __restrict__ sums, int nimg, int H, int W) {
   __shared__ float ga[TY + 2 * R][TX + 2 * R + 1];
   __shared__ float gb[TY + 2 * R][TX + 2 * R + 1];
   __shared__ float red[2 * (TX * TY / 64)];
-  const int b = blockIdx.z, ty0 = blockIdx.y * TY, tx0 = blockIdx.x * TX;
+  int btx_, bty_, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) return;
+  const int ty0 = bty_ * TY, tx0 = btx_ * TX;
   const long ims = 3L * H * W;
   load_gray_tile<R>(ga, im_a + b * ims, H, W, ty0, tx0);
   load_gray_tile<R>(gb, im_b + b * ims, H, W, ty0, tx0);
@@ -98,11 +100,13 @@ __global__ __launch_bounds__(TX* TY) void census_bwd_kernel(const float* __restr
                                                             const float* __restrict__ im_b,
                                                             const float* __restrict__ gham,
                                                             const float* __restrict__ scale,
-                                                            float* __restrict__ g_im_b, int H, int W) {
+                                                            float* __restrict__ g_im_b, int nimg, int H, int W) {
   __shared__ float ga[TY + 2 * R][TX + 2 * R + 1];
   __shared__ float gb[TY + 2 * R][TX + 2 * R + 1];
   __shared__ float gg[TY + 2 * R][TX + 2 * R + 1];
-  const int b = blockIdx.z, ty0 = blockIdx.y * TY, tx0 = blockIdx.x * TX;
+  int btx_, bty_, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) return;
+  const int ty0 = bty_ * TY, tx0 = btx_ * TX;
   const long ims = 3L * H * W;
   load_gray_tile<R>(ga, im_a + b * ims, H, W, ty0, tx0);
   load_gray_tile<R>(gb, im_b + b * ims, H, W, ty0, tx0);
@@ -183,11 +187,13 @@ __global__ __launch_bounds__(TX* TY) void photo_fwd_kernel(const float* __restri
                                                            const float* __restrict__ rec,
                                                            const float* __restrict__ mask,
                                                            float* __restrict__ ssim_map,
-                                                           float* __restrict__ sums, int C, int H, int W) {
+                                                           float* __restrict__ sums, int nimg, int C, int H, int W) {
   __shared__ float tx[TY + 2][TX + 3];  // x = recons*mask
   __shared__ float ty[TY + 2][TX + 3];  // y = im*mask
   __shared__ float red[3 * (TX * TY / 64)];
-  const int b = blockIdx.z, ty0 = blockIdx.y * TY, tx0 = blockIdx.x * TX;
+  int btx_, bty_, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) return;
+  const int ty0 = bty_ * TY, tx0 = btx_ * TX;
   const long cs = (long)H * W;
   const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
   const int x = tx0 + lx, y = ty0 + ly;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(TX* TY) void photo_bwd_kernel(const float* __restri
                                                            const float* __restrict__ mask,
                                                            const float* __restrict__ gmap,
                                                            const float* __restrict__ coef,
-                                                           float* __restrict__ g_rec, int C, int H, int W) {
+                                                           float* __restrict__ g_rec, int nimg, int C, int H, int W) {
   // data region: pixels (ty0-2 .. ty0+TY+1) x (tx0-2 .. tx0+TX+1); windows anchored at
   // (ty0-2 .. ty0+TY-1) x (tx0-2 .. tx0+TX-1)
   __shared__ float dx_[TY + 4][TX + 5];
@@ -245,7 +251,9 @@ __global__ __launch_bounds__(TX* TY) void photo_bwd_kernel(const float* __restri
   __shared__ float wa[TY + 2][TX + 3];
   __shared__ float wb[TY + 2][TX + 3];
   __shared__ float wc[TY + 2][TX + 3];
-  const int b = blockIdx.z, ty0 = blockIdx.y * TY, tx0 = blockIdx.x * TX;
+  int btx_, bty_, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) return;
+  const int ty0 = bty_ * TY, tx0 = btx_ * TX;
   const long cs = (long)H * W;
   const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
   const int x = tx0 + lx, y = ty0 + ly;
@@ -328,11 +336,11 @@ extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const flo
     hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
     if (e != hipSuccess) return af_hip_status(e);
   }
-  dim3 grid(af_cdiv(W, TX), af_cdiv(H, TY), B);
+  dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
   switch (radius) {
-    case 1: hipLaunchKernelGGL(census_fwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, H, W); break;
-    case 2: hipLaunchKernelGGL(census_fwd_kernel<2>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, H, W); break;
-    default: hipLaunchKernelGGL(census_fwd_kernel<3>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, H, W); break;
+    case 1: hipLaunchKernelGGL(census_fwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
+    case 2: hipLaunchKernelGGL(census_fwd_kernel<2>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
+    default: hipLaunchKernelGGL(census_fwd_kernel<3>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
   }
   return af_launch_status();
 }
@@ -346,11 +354,11 @@ extern "C" int arflow_census_bwd(const float* im_a, const float* im_b, const flo
   AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 8 * 65535, ARFLOW_ESHAPE);
   AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(af_cdiv(W, TX), af_cdiv(H, TY), B);
+  dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
   switch (radius) {
-    case 1: hipLaunchKernelGGL(census_bwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, gham, scale, g_im_b, H, W); break;
-    case 2: hipLaunchKernelGGL(census_bwd_kernel<2>, grid, dim3(TX * TY), 0, st, im_a, im_b, gham, scale, g_im_b, H, W); break;
-    default: hipLaunchKernelGGL(census_bwd_kernel<3>, grid, dim3(TX * TY), 0, st, im_a, im_b, gham, scale, g_im_b, H, W); break;
+    case 1: hipLaunchKernelGGL(census_bwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, gham, scale, g_im_b, B, H, W); break;
+    case 2: hipLaunchKernelGGL(census_bwd_kernel<2>, grid, dim3(TX * TY), 0, st, im_a, im_b, gham, scale, g_im_b, B, H, W); break;
+    default: hipLaunchKernelGGL(census_bwd_kernel<3>, grid, dim3(TX * TY), 0, st, im_a, im_b, gham, scale, g_im_b, B, H, W); break;
   }
   return af_launch_status();
 }
@@ -364,8 +372,8 @@ extern "C" int arflow_photo_fwd(const float* im, const float* recons, const floa
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
   if (e != hipSuccess) return af_hip_status(e);
-  dim3 grid(af_cdiv(W, TX), af_cdiv(H, TY), B);
-  hipLaunchKernelGGL(photo_fwd_kernel, grid, dim3(TX * TY), 0, st, im, recons, mask, ssim_map, sums, C, H, W);
+  dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
+  hipLaunchKernelGGL(photo_fwd_kernel, grid, dim3(TX * TY), 0, st, im, recons, mask, ssim_map, sums, B, C, H, W);
   return af_launch_status();
 }
 
@@ -377,8 +385,8 @@ extern "C" int arflow_photo_bwd(const float* im, const float* recons, const floa
   AF_REQUIRE_PTR(coef);
   AF_REQUIRE_PTR(g_recons);
   AF_REQUIRE(B > 0 && C > 0 && H >= 3 && W >= 3 && B <= 65535, ARFLOW_ESHAPE);
-  dim3 grid(af_cdiv(W, TX), af_cdiv(H, TY), B);
+  dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
   hipLaunchKernelGGL(photo_bwd_kernel, grid, dim3(TX * TY), 0, (hipStream_t)stream, im, recons, mask, gmap,
-                     coef, g_recons, C, H, W);
+                     coef, g_recons, B, C, H, W);
   return af_launch_status();
 }
