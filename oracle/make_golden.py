@@ -281,6 +281,30 @@ def gen_models():
     save('models', **out)
 
 
+def gen_examples():
+    """BASELINE config 1: the reference's example images (examples/img{0,1,2}.png, 1242x375) resized to
+    384x640 as the README prescribes, through the reference PWCLite (2- and 3-frame) with deterministic
+    weights, on CPU.  The images are data files the reference ships; stored as uint8 arrays."""
+    import models.pwclite as mp
+    from PIL import Image
+    frames = []
+    for n in ('img0.png', 'img1.png', 'img2.png'):
+        im = Image.open(os.path.join(REF, 'examples', n)).convert('RGB').resize((640, 384), Image.BILINEAR)
+        frames.append(torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1))
+    u8 = torch.cat(frames, 0).unsqueeze(0)  # [1,9,384,640] uint8
+    x = u8.float() / 255
+    out = {'frames_u8': u8}
+    m2 = fill_deterministic(mp.PWCLite(Cfg(upsample=True, n_frames=2, reduce_dense=True))).eval()
+    r2 = m2(x[:, 3:9], with_bk=True)
+    m3 = fill_deterministic(mp.PWCLite(Cfg(upsample=True, n_frames=3, reduce_dense=True))).eval()
+    r3 = m3(x)
+    for tag, r in (('two', r2), ('three', r3)):
+        for k in ('flows_fw', 'flows_bw'):
+            out['%s_%s_full_pooled8' % (tag, k)] = torch.nn.functional.avg_pool2d(r[k][0], 8)
+            out['%s_%s_quarter' % (tag, k)] = r[k][1] if r[k][1].shape[2] == 96 else torch.nn.functional.avg_pool2d(r[k][1], 2)
+    save('examples', **out)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='all')
@@ -297,3 +321,5 @@ if __name__ == '__main__':
             gen_losses()
         if args.only in ('all', 'models'):
             gen_models()
+        if args.only in ('all', 'examples'):
+            gen_examples()
