@@ -337,7 +337,7 @@ extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, int
   AF_REQUIRE(max_disp >= 1, ARFLOW_EPARAM);
   AF_REQUIRE(B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  if (corr_v2::eligible(C, W, max_disp) && W >= 24 && H >= 6) return corr_v2::launch_fwd(x1, x2, out, B, C, H, W, st);
+  if (corr_v2::eligible(C, W, max_disp)) return corr_v2::launch_fwd(x1, x2, out, B, C, H, W, st);
   switch (max_disp) {
     case 1: return dispatch_fwd<1>(x1, x2, out, B, C, H, W, st);
     case 2: return dispatch_fwd<2>(x1, x2, out, B, C, H, W, st);
@@ -362,7 +362,7 @@ extern "C" int arflow_corr_bwd(const float* gout, const float* x1, const float* 
   AF_REQUIRE(max_disp >= 1, ARFLOW_EPARAM);
   AF_REQUIRE(2 * B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  if (corr_v2::eligible(C, W, max_disp) && W >= 24 && H >= 6)
+  if (corr_v2::eligible(C, W, max_disp))
     return corr_v2::launch_bwd(gout, x1, x2, gx1, gx2, B, C, H, W, st);
   switch (max_disp) {
     case 1: return dispatch_bwd<1>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
