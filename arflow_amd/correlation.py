@@ -24,13 +24,15 @@ class Correlation(nn.Module):
         self.output_dim = 2 * self.max_displacement + 1
         self.pad_size = self.max_displacement
 
-    def forward(self, x1, x2):
-        return AF.correlation(x1, x2, self.max_displacement)
+    def forward(self, x1, x2, negative_slope=1.0):
+        """``negative_slope`` != 1 fuses the LeakyReLU the callers apply to the volume
+        (models/pwclite.py:183-184) into the kernel; the default is the reference's plain volume."""
+        return AF.correlation(x1, x2, self.max_displacement, negative_slope)
 
 
-def compute_cost_volume(features1, features2, max_displacement):
-    """models/uflow_model.py:53-92 (same arithmetic as Correlation, NCHW)."""
+def compute_cost_volume(features1, features2, max_displacement, negative_slope=1.0):
+    """models/uflow_model.py:53-92 (same arithmetic as Correlation, NCHW); optional fused LeakyReLU."""
     _, _, height, _ = features1.shape
     if max_displacement <= 0 or max_displacement >= height:
         raise ValueError(f'Max displacement of {max_displacement} is too large.')
-    return AF.correlation(features1, features2, max_displacement)
+    return AF.correlation(features1, features2, max_displacement, negative_slope)

@@ -63,7 +63,7 @@ template <int D, int PX, int TW, int CC>
 // two workgroups (2N waves) per CU: ceil(2N/4) waves per SIMD bounds the VGPR budget
 __global__ __launch_bounds__(64 * (2 * D + 1), (2 * (2 * D + 1) + 3) / 4) void corr_fwd_kernel(
     const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ out, int C, int H,
-    int W, float inv_c) {
+    int W, float inv_c, float slope) {
   using K = FwdCfg<D, PX, TW, CC>;
   constexpr int N = K::N, TH = K::TH, R2 = K::R2, P2 = K::P2;
   __shared__ __attribute__((aligned(16))) float lds[K::LDS_FLOATS];
@@ -120,6 +120,13 @@ __global__ __launch_bounds__(64 * (2 * D + 1), (2 * (2 * D + 1) + 3) / 4) void c
 
   const int gy = ty0 + ry, gx = tx0 + sx;
   if (gy >= H) return;
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      const float v = acc[j][p] * inv_c;
+      acc[j][p] = v > 0.f ? v : v * slope;
+    }
   float* ob = out + (((long)b * N * N + wave * N) * H + gy) * W + gx;
   const long cs = (long)H * W;
   if ((PX % 4 == 0) && (W % 4 == 0) && gx + PX <= W) {
@@ -128,24 +135,23 @@ __global__ __launch_bounds__(64 * (2 * D + 1), (2 * (2 * D + 1) + 3) / 4) void c
 #pragma unroll
       for (int q = 0; q < PX / 4; ++q)
         *reinterpret_cast<float4*>(ob + j * cs + 4 * q) =
-            make_float4(acc[j][4 * q] * inv_c, acc[j][4 * q + 1] * inv_c, acc[j][4 * q + 2] * inv_c,
-                        acc[j][4 * q + 3] * inv_c);
+            make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
   } else {
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
       for (int p = 0; p < PX; ++p)
-        if (gx + p < W) ob[j * cs + p] = acc[j][p] * inv_c;
+        if (gx + p < W) ob[j * cs + p] = acc[j][p];
   }
 }
 
 template <int D, int PX, int TW, int CC>
-int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W,
+int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, float slope,
                hipStream_t st) {
   using K = FwdCfg<D, PX, TW, CC>;
   dim3 grid(af_cdiv(W, TW), af_cdiv(H, K::TH), B);
   hipLaunchKernelGGL((corr_fwd_kernel<D, PX, TW, CC>), grid, dim3(K::NT), 0, st, x1, x2, out, C, H, W,
-                     1.0f / (float)C);
+                     1.0f / (float)C, slope);
   return af_launch_status();
 }
 
@@ -165,6 +171,7 @@ struct BwdCfg {
 
 template <int D, int PX, int TW, int CC, int NT>
 __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict__ gout,
+                                                     const float* __restrict__ fout, float slope,
                                                      const float* __restrict__ x1,
                                                      const float* __restrict__ x2,
                                                      float* __restrict__ gx1, float* __restrict__ gx2,
@@ -182,7 +189,12 @@ __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict
   const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * H * W;
   float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * H * W;
   const float* gb = gout + (long)b * N * N * H * W;
+  const float* fb = fout ? fout + (long)b * N * N * H * W : nullptr;
   const long cs = (long)H * W;
+  auto gval = [&](long off) {  // output gradient through the fused LeakyReLU
+    const float v = gb[off];
+    return (fb && !(fb[off] > 0.f)) ? v * slope : v;
+  };
 
   // output gradients of this lane's pixels, read once
   float g[N][N][PX];
@@ -193,14 +205,14 @@ __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict
       if (mode == 0) {
 #pragma unroll
         for (int p = 0; p < PX; ++p)
-          g[i][j][p] = (gy < H && gx + p < W) ? gb[(i * N + j) * cs + (long)gy * W + gx + p] : 0.f;
+          g[i][j][p] = (gy < H && gx + p < W) ? gval((i * N + j) * cs + (long)gy * W + gx + p) : 0.f;
       } else {
         const int yy = gy + i - D;
         const int ch = (N - 1 - i) * N + (N - 1 - j);
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
           const int xx = gx + p + j - D;
-          g[i][j][p] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? gb[ch * cs + (long)yy * W + xx] : 0.f;
+          g[i][j][p] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? gval(ch * cs + (long)yy * W + xx) : 0.f;
         }
       }
     }
@@ -244,13 +256,13 @@ __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict
 }
 
 template <int D, int PX, int TW, int CC, int NT>
-int launch_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2, int B, int C,
-               int H, int W, hipStream_t st) {
+int launch_bwd(const float* gout, const float* fout, float slope, const float* x1, const float* x2, float* gx1,
+               float* gx2, int B, int C, int H, int W, hipStream_t st) {
   using K = BwdCfg<D, PX, TW, CC, NT>;
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
   dim3 grid(af_cdiv(W, TW), af_cdiv(H, K::TH), B * nmodes);
-  hipLaunchKernelGGL((corr_bwd_kernel<D, PX, TW, CC, NT>), grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B,
+  hipLaunchKernelGGL((corr_bwd_kernel<D, PX, TW, CC, NT>), grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B,
                      C, H, W, 1.0f / (float)C, gx1 ? 0 : 1);
   return af_launch_status();
 }
@@ -260,7 +272,7 @@ int launch_bwd(const float* gout, const float* x1, const float* x2, float* gx1, 
 // (every model in the reference uses max_displacement = 4, models/pwclite.py:124-126).
 // ------------------------------------------------------------------------------------------------
 __global__ void corr_fwd_generic(const float* __restrict__ x1, const float* __restrict__ x2,
-                                 float* __restrict__ out, int B, int C, int H, int W, int D) {
+                                 float* __restrict__ out, int B, int C, int H, int W, int D, float slope) {
   const int N = 2 * D + 1;
   const long total = (long)B * N * N * H * W;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -274,11 +286,13 @@ __global__ void corr_fwd_generic(const float* __restrict__ x1, const float* __re
     if (yy >= 0 && yy < H && xx >= 0 && xx < W)
       for (int c = 0; c < C; ++c)
         s = fmaf(x1[(((long)b * C + c) * H + y) * W + x], x2[(((long)b * C + c) * H + yy) * W + xx], s);
-    out[idx] = s / (float)C;
+    const float v = s / (float)C;
+    out[idx] = v > 0.f ? v : v * slope;
   }
 }
 
-__global__ void corr_bwd_generic(const float* __restrict__ gout, const float* __restrict__ x1,
+__global__ void corr_bwd_generic(const float* __restrict__ gout, const float* __restrict__ fout, float slope,
+                                 const float* __restrict__ x1,
                                  const float* __restrict__ x2, float* __restrict__ gx1,
                                  float* __restrict__ gx2, int B, int C, int H, int W, int D) {
   const int N = 2 * D + 1;
@@ -290,6 +304,11 @@ __global__ void corr_bwd_generic(const float* __restrict__ gout, const float* __
     const int c = (idx / ((long)W * H)) % C;
     const int b = idx / ((long)W * H * C);
     const float* gb = gout + (long)b * N * N * H * W;
+    const float* fb = fout ? fout + (long)b * N * N * H * W : nullptr;
+    auto gval = [&](long off) {
+      const float v = gb[off];
+      return (fb && !(fb[off] > 0.f)) ? v * slope : v;
+    };
     const float* p1 = x1 + ((long)b * C + c) * H * W;
     const float* p2 = x2 + ((long)b * C + c) * H * W;
     float s1 = 0.f, s2 = 0.f;
@@ -297,10 +316,10 @@ __global__ void corr_bwd_generic(const float* __restrict__ gout, const float* __
       for (int j = 0; j < N; ++j) {
         const int ya = y + i - D, xa = x + j - D;  // gx1: x2 at the shifted position
         if (ya >= 0 && ya < H && xa >= 0 && xa < W)
-          s1 = fmaf(gb[((long)(i * N + j) * H + y) * W + x], p2[(long)ya * W + xa], s1);
+          s1 = fmaf(gval(((long)(i * N + j) * H + y) * W + x), p2[(long)ya * W + xa], s1);
         const int yb = y - i + D, xb = x - j + D;  // gx2: gout and x1 at the un-shifted position
         if (yb >= 0 && yb < H && xb >= 0 && xb < W)
-          s2 = fmaf(gb[((long)(i * N + j) * H + yb) * W + xb], p1[(long)yb * W + xb], s2);
+          s2 = fmaf(gval(((long)(i * N + j) * H + yb) * W + xb), p1[(long)yb * W + xb], s2);
       }
     if (gx1) gx1[idx] = s1 / (float)C;
     if (gx2) gx2[idx] = s2 / (float)C;
@@ -308,28 +327,29 @@ __global__ void corr_bwd_generic(const float* __restrict__ gout, const float* __
 }
 
 template <int D>
-int dispatch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W,
+int dispatch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, float slope,
                  hipStream_t st) {
   // pick the widest lane strip that still yields enough workgroups to occupy the chip
   const long px = (long)B * H * W;
-  if (W >= 24 && px >= 32768) return launch_fwd<D, 8, 32, 8>(x1, x2, out, B, C, H, W, st);
-  if (W >= 12 && px >= 8192) return launch_fwd<D, 4, 16, 8>(x1, x2, out, B, C, H, W, st);
-  return launch_fwd<D, 2, 16, 8>(x1, x2, out, B, C, H, W, st);
+  if (W >= 24 && px >= 32768) return launch_fwd<D, 8, 32, 8>(x1, x2, out, B, C, H, W, slope, st);
+  if (W >= 12 && px >= 8192) return launch_fwd<D, 4, 16, 8>(x1, x2, out, B, C, H, W, slope, st);
+  return launch_fwd<D, 2, 16, 8>(x1, x2, out, B, C, H, W, slope, st);
 }
 
 template <int D>
-int dispatch_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2, int B,
-                 int C, int H, int W, hipStream_t st) {
+int dispatch_bwd(const float* gout, const float* fout, float slope, const float* x1, const float* x2, float* gx1,
+                 float* gx2, int B, int C, int H, int W, hipStream_t st) {
   const long px = (long)B * H * W;
-  if (W >= 48 && px >= 65536) return launch_bwd<D, 2, 64, 8, 256>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
-  if (W >= 24 && px >= 8192) return launch_bwd<D, 2, 32, 8, 128>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
-  return launch_bwd<D, 1, 16, 8, 64>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
+  if (W >= 48 && px >= 65536) return launch_bwd<D, 2, 64, 8, 256>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+  if (W >= 24 && px >= 8192) return launch_bwd<D, 2, 32, 8, 128>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+  return launch_bwd<D, 1, 16, 8, 64>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
 }
 
 }  // namespace
 
 extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W,
-                               int max_disp, arflow_stream_t stream) {
+                               int max_disp, float negative_slope, arflow_stream_t stream) {
+  const float slope = negative_slope;
   AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
   AF_REQUIRE_PTR(out);
@@ -337,25 +357,29 @@ extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, int
   AF_REQUIRE(max_disp >= 1, ARFLOW_EPARAM);
   AF_REQUIRE(B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  if (corr_v2::eligible(C, W, max_disp)) return corr_v2::launch_fwd(x1, x2, out, B, C, H, W, st);
+  if (corr_v2::eligible(C, W, max_disp)) return corr_v2::launch_fwd(x1, x2, out, B, C, H, W, slope, st);
   switch (max_disp) {
-    case 1: return dispatch_fwd<1>(x1, x2, out, B, C, H, W, st);
-    case 2: return dispatch_fwd<2>(x1, x2, out, B, C, H, W, st);
-    case 3: return dispatch_fwd<3>(x1, x2, out, B, C, H, W, st);
-    case 4: return dispatch_fwd<4>(x1, x2, out, B, C, H, W, st);
+    case 1: return dispatch_fwd<1>(x1, x2, out, B, C, H, W, slope, st);
+    case 2: return dispatch_fwd<2>(x1, x2, out, B, C, H, W, slope, st);
+    case 3: return dispatch_fwd<3>(x1, x2, out, B, C, H, W, slope, st);
+    case 4: return dispatch_fwd<4>(x1, x2, out, B, C, H, W, slope, st);
     default: {
       const int N = 2 * max_disp + 1;
       const long total = (long)B * N * N * H * W;
       hipLaunchKernelGGL(corr_fwd_generic, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)),
-                         dim3(256), 0, st, x1, x2, out, B, C, H, W, max_disp);
+                         dim3(256), 0, st, x1, x2, out, B, C, H, W, max_disp, slope);
       return af_launch_status();
     }
   }
 }
 
-extern "C" int arflow_corr_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2,
-                               int B, int C, int H, int W, int max_disp, arflow_stream_t stream) {
+extern "C" int arflow_corr_bwd(const float* gout, const float* out, const float* x1, const float* x2, float* gx1,
+                               float* gx2, int B, int C, int H, int W, int max_disp, float negative_slope,
+                               arflow_stream_t stream) {
   AF_REQUIRE_PTR(gout);
+  const float slope = negative_slope;
+  const float* fout = negative_slope != 1.0f ? out : nullptr;
+  if (negative_slope != 1.0f) AF_REQUIRE_PTR(out);
   AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
   AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, ARFLOW_ESHAPE);
@@ -363,16 +387,16 @@ extern "C" int arflow_corr_bwd(const float* gout, const float* x1, const float* 
   AF_REQUIRE(2 * B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
   if (corr_v2::eligible(C, W, max_disp))
-    return corr_v2::launch_bwd(gout, x1, x2, gx1, gx2, B, C, H, W, st);
+    return corr_v2::launch_bwd(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
   switch (max_disp) {
-    case 1: return dispatch_bwd<1>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
-    case 2: return dispatch_bwd<2>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
-    case 3: return dispatch_bwd<3>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
-    case 4: return dispatch_bwd<4>(gout, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 1: return dispatch_bwd<1>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 2: return dispatch_bwd<2>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 3: return dispatch_bwd<3>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 4: return dispatch_bwd<4>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
     default: {
       const long total = (long)B * C * H * W;
       hipLaunchKernelGGL(corr_bwd_generic, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)),
-                         dim3(256), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, max_disp);
+                         dim3(256), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, max_disp);
       return af_launch_status();
     }
   }

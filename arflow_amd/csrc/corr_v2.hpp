@@ -104,7 +104,7 @@ inline unsigned grid_for_tiles(int T) { return 8u * (unsigned)((T + 7) / 8); }
 template <int NBUF>
 __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                     float* __restrict__ out, int nimg, int C, int H, int W,
-                                                    float inv_c) {
+                                                    float inv_c, float slope) {
   constexpr int BUF = SRC_FLOATS + X1_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + TH * SP];  // + pad: prefetch runs a channel ahead
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -197,16 +197,23 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-      *reinterpret_cast<float4*>(ob + (k * N + j) * cs) =
-          make_float4(acc[k][j][0] * inv_c, acc[k][j][1] * inv_c, acc[k][j][2] * inv_c, acc[k][j][3] * inv_c);
+    for (int j = 0; j < N; ++j) {
+      float v[PX];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        v[p] = acc[k][j][p] * inv_c;
+        v[p] = v[p] > 0.f ? v[p] : v[p] * slope;  // fused LeakyReLU (slope 1 = identity)
+      }
+      *reinterpret_cast<float4*>(ob + (k * N + j) * cs) = make_float4(v[0], v[1], v[2], v[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // mode 0: gx1[c,p] = (1/C) sum_{i,j} g[i*9+j][p]        * x2[c][p+(i-4,j-4)]
 // mode 1: gx2[c,q] = (1/C) sum_{i,j} g[80-(i*9+j)][q+(i-4,j-4)] * x1[c][q+(i-4,j-4)]
 template <int NBUF>
-__global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x1,
+__global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ gout, const float* __restrict__ fout,
+                                                    float slope, const float* __restrict__ x1,
                                                     const float* __restrict__ x2, float* __restrict__ gx1,
                                                     float* __restrict__ gx2, int B, int C, int H, int W,
                                                     float inv_c, int mode_base, int nmodes) {
@@ -237,7 +244,17 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * cs;
   float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * cs;
   const float* gb = gout + (long)b * N * N * cs;
+  const float* fb = fout ? fout + (long)b * N * N * cs : nullptr;  // forward output: LeakyReLU derivative
   const int gy = ty0 + y, gx = tx0 + 4 * xg;
+  auto load4 = [&](long off) {  // 4 output gradients through the fused LeakyReLU
+    float4 t = *reinterpret_cast<const float4*>(gb + off);
+    if (fb) {
+      const float4 f = *reinterpret_cast<const float4*>(fb + off);
+      t.x = f.x > 0.f ? t.x : t.x * slope, t.y = f.y > 0.f ? t.y : t.y * slope;
+      t.z = f.z > 0.f ? t.z : t.z * slope, t.w = f.w > 0.f ? t.w : t.w * slope;
+    }
+    return t;
+  };
 
   // 10 DMA instructions per chunk over 3 waves: every wave issues 4 (the surplus two re-send piece 9,
   // identical bytes to the same LDS block) so that the per-wave count is a compile-time constant
@@ -270,28 +287,26 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
     for (int j = 0; j < N; ++j) {
       if (mode == 0) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy < H && gx < W) t = *reinterpret_cast<const float4*>(gb + (i * N + j) * cs + (long)gy * W + gx);
+        if (gy < H && gx < W) t = load4((i * N + j) * cs + (long)gy * W + gx);
         g[k][j][0] = t.x, g[k][j][1] = t.y, g[k][j][2] = t.z, g[k][j][3] = t.w;
       } else {
         // 4 consecutive pixels starting at gx + (j-4): one or two ALIGNED float4 loads (gx and W are
         // multiples of 4, so an aligned block is entirely inside or outside a row) + a compile-time
         // register shift, instead of 4 bounds-checked scalar loads
         const int yy = gy + i - D;
-        const float* gr = gb + (N * N - 1 - (i * N + j)) * cs + (long)yy * W;
+        const long gro = (N * N - 1 - (i * N + j)) * cs + (long)yy * W;
         const bool rowok = yy >= 0 && yy < H;
-        constexpr int dummy = 0;
-        (void)dummy;
         const int e = j - D;                       // -4 .. 4 (compile-time after unrolling)
         const int blo = (e >= 0 ? e / 4 : -((3 - e) / 4)) * 4;  // 4*floor(e/4)
         const int sh = e - blo;                    // 0..3
         float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
         const int xlo = gx + blo, xhi = xlo + 4;
         if (rowok && xlo >= 0 && xlo < W) {
-          const float4 t = *reinterpret_cast<const float4*>(gr + xlo);
+          const float4 t = load4(gro + xlo);
           lo[0] = t.x, lo[1] = t.y, lo[2] = t.z, lo[3] = t.w;
         }
         if (sh != 0 && rowok && xhi >= 0 && xhi < W) {
-          const float4 t = *reinterpret_cast<const float4*>(gr + xhi);
+          const float4 t = load4(gro + xhi);
           hi[0] = t.x, hi[1] = t.y, hi[2] = t.z, hi[3] = t.w;
         }
 #pragma unroll
@@ -353,29 +368,30 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 
 inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
 
-inline int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, hipStream_t st) {
+inline int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, float slope,
+                      hipStream_t st) {
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B;
   dim3 grid(grid_for_tiles(tiles));
   // many tiles: 4 workgroups per CU hide each other's DMA latency, keep LDS small (2 buffers);
   // few tiles: one workgroup per CU -> deeper ring so its own DMA runs 3 chunks ahead
   if (tiles >= 768)
-    hipLaunchKernelGGL(fwd_kernel<2>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C);
+    hipLaunchKernelGGL(fwd_kernel<2>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C, slope);
   else
-    hipLaunchKernelGGL(fwd_kernel<4>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C);
+    hipLaunchKernelGGL(fwd_kernel<4>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C, slope);
   return af_launch_status();
 }
 
-inline int launch_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2, int B, int C,
-                      int H, int W, hipStream_t st) {
+inline int launch_bwd(const float* gout, const float* fout, float slope, const float* x1, const float* x2,
+                      float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st) {
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B * nmodes;
   dim3 grid(grid_for_tiles(tiles));
   if (tiles >= 768)
-    hipLaunchKernelGGL(bwd_kernel<2>, grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
+    hipLaunchKernelGGL(bwd_kernel<2>, grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
                        gx1 ? 0 : 1, nmodes);
   else
-    hipLaunchKernelGGL(bwd_kernel<4>, grid, dim3(NT), 0, st, gout, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
+    hipLaunchKernelGGL(bwd_kernel<4>, grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
                        gx1 ? 0 : 1, nmodes);
   return af_launch_status();
 }

@@ -95,35 +95,42 @@ class CorrelationFunction(torch.autograd.Function):
     models/correlation_native.py:13-23."""
 
     @staticmethod
-    def forward(ctx, x1, x2, max_displacement):
+    def forward(ctx, x1, x2, max_displacement, negative_slope=1.0):
         _need_gpu(x1, x2)
         x1, x2 = x1.contiguous(), x2.contiguous()
         if x1.shape != x2.shape or x1.dim() != 4:
             raise ValueError('correlation expects two [B,C,H,W] tensors of equal shape')
         B, C, H, W = x1.shape
         d = int(max_displacement)
+        slope = float(negative_slope)
         out = torch.empty(B, (2 * d + 1) ** 2, H, W, device=x1.device, dtype=torch.float32)
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, W, d, _stream(), key=(B, C, H, W, d))
-        ctx.save_for_backward(x1, x2)
-        ctx.d = d
+            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, W, d, slope, _stream(), key=(B, C, H, W, d))
+        if slope != 1.0:
+            ctx.save_for_backward(x1, x2, out)  # the sign of the output selects the LeakyReLU derivative
+        else:
+            ctx.save_for_backward(x1, x2)
+        ctx.d, ctx.slope = d, slope
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x1, x2 = ctx.saved_tensors
+        x1, x2 = ctx.saved_tensors[:2]
+        fout = ctx.saved_tensors[2] if ctx.slope != 1.0 else None
         B, C, H, W = x1.shape
         gout = gout.contiguous()
         g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_bwd', _p(gout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, W, ctx.d, _stream(),
-                  key=(B, C, H, W, ctx.d))
-        return g1, g2, None
+            _call('arflow_corr_bwd', _p(gout), _p(fout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, W, ctx.d, ctx.slope,
+                  _stream(), key=(B, C, H, W, ctx.d, fout is not None))
+        return g1, g2, None, None
 
 
-def correlation(x1, x2, max_displacement=4):
-    return CorrelationFunction.apply(x1, x2, max_displacement)
+def correlation(x1, x2, max_displacement=4, negative_slope=1.0):
+    """Cost volume, optionally with the LeakyReLU every caller applies right after it fused into the
+    kernel's store stage (and its derivative into the backward's load stage)."""
+    return CorrelationFunction.apply(x1, x2, max_displacement, negative_slope)
 
 
 # ------------------------------------------------------------------------------------------------

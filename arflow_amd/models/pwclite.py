@@ -49,7 +49,7 @@ class PWCLite(nn.Module):
             else:
                 flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
                 x2_warp = flow_warp(x2, flow)
-            out_corr_relu = self.leakyRELU(self.corr(x1, x2_warp))
+            out_corr_relu = self.corr(x1, x2_warp, negative_slope=0.1)  # corr + LeakyReLU(0.1) in one kernel
             x1_1by1 = self.conv_1x1[l](x1)
             x_intm, flow_res = self.flow_estimators(torch.cat([out_corr_relu, x1_1by1, flow], dim=1))
             flow = flow + flow_res
@@ -74,8 +74,8 @@ class PWCLite(nn.Module):
                 flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
                 x0_warp = flow_warp(x0, flow[:, :2])
                 x2_warp = flow_warp(x2, flow[:, 2:])
-            corr_relu_10 = self.leakyRELU(self.corr(x1, x0_warp))
-            corr_relu_12 = self.leakyRELU(self.corr(x1, x2_warp))
+            corr_relu_10 = self.corr(x1, x0_warp, negative_slope=0.1)
+            corr_relu_12 = self.corr(x1, x2_warp, negative_slope=0.1)
             x1_1by1 = self.conv_1x1[l](x1)
             feat_10 = [x1_1by1, corr_relu_10, corr_relu_12, flow[:, :2], -flow[:, 2:]]
             feat_12 = [x1_1by1, corr_relu_12, corr_relu_10, flow[:, 2:], -flow[:, :2]]

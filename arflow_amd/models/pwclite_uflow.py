@@ -80,7 +80,7 @@ class PWCLiteUflow(nn.Module):
                 x2_warp = flow_warp(x2, flow, align_corners=self.align_corners, pad=self.warp_pad)
             if self.feature_norm:
                 x1, x2_warp = normalize_features([x1, x2_warp])
-            out_corr_relu = self.leakyRELU(self.corr(x1, x2_warp))
+            out_corr_relu = self.corr(x1, x2_warp, negative_slope=0.1)  # corr + LeakyReLU(0.1) in one kernel
             if l == 0:
                 act, flow_res = self.flow_estimators[l](torch.cat([out_corr_relu, x1, flow], dim=1))
             else:

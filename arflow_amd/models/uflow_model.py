@@ -118,8 +118,8 @@ class PWCFlow(nn.Module):
             f1n, w2n = normalize_features([features1, warped2], normalize=self._normalize_before_cost_volume,
                                           center=self._normalize_before_cost_volume,
                                           moments_across_channels=True, moments_across_images=True)
-            cost_volume = func.leaky_relu(compute_cost_volume(f1n, w2n, max_displacement=4),
-                                          negative_slope=self._leaky_relu_alpha)
+            cost_volume = compute_cost_volume(f1n, w2n, max_displacement=4,
+                                              negative_slope=self._leaky_relu_alpha)  # fused LeakyReLU
             if flow_up is None:
                 x_in = torch.cat([cost_volume, features1], dim=1)
             else:

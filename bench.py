@@ -36,8 +36,9 @@ def algorithmic_bytes(name, shape):
         B, C, H, W, d = shape
         return 4 * B * H * W * (2 * C + (2 * d + 1) ** 2)
     if name == 'arflow_corr_bwd':
-        B, C, H, W, d = shape
-        return 4 * B * H * W * ((2 * d + 1) ** 2 + 4 * C)
+        B, C, H, W, d = shape[:5]
+        fused = len(shape) > 5 and shape[5]  # fused LeakyReLU: the forward output is read as well
+        return 4 * B * H * W * ((2 * d + 1) ** 2 * (2 if fused else 1) + 4 * C)
     if name == 'arflow_warp_fwd':
         B, C, H, W = shape
         return 4 * B * H * W * (2 * C + 2)

@@ -68,12 +68,18 @@ const char* arflow_strerror(int code);
  * (models/correlation_native.py:13-23) and compute_cost_volume (models/uflow_model.py:53-92).
  * x1,x2: [B,C,H,W]; out: [B,(2d+1)^2,H,W]; 1 <= max_disp. */
 int arflow_corr_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W,
-                    int max_disp, arflow_stream_t stream);
+                    int max_disp, float negative_slope, arflow_stream_t stream);
+/* negative_slope: fused LeakyReLU on the cost volume, out = v > 0 ? v : negative_slope * v -- the
+ * activation every caller applies right after the correlation (models/pwclite.py:183-184,
+ * models/uflow_model.py:180); 1.0f = plain cost volume. */
 
 /* Gradients of the above (correlation_cuda.backward, correlation_cuda.cc:89-167; kernels
  * correlation_cuda_kernel.cu:116-300).  gx1 / gx2 may be NULL to skip that gradient. */
-int arflow_corr_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2,
-                    int B, int C, int H, int W, int max_disp, arflow_stream_t stream);
+int arflow_corr_bwd(const float* gout, const float* out, const float* x1, const float* x2, float* gx1,
+                    float* gx2, int B, int C, int H, int W, int max_disp, float negative_slope,
+                    arflow_stream_t stream);
+/* With negative_slope != 1 the forward OUTPUT must be passed as `out` (its sign selects the LeakyReLU
+ * derivative, exactly as torch's in-place leaky_relu backward does); otherwise `out` may be NULL. */
 
 /* ---- bilinear warp ----------------------------------------------------------------------------
  * out[b,c,y,x] = bilinear(src[b,c], x + flow[b,0,y,x], y + flow[b,1,y,x]) with torch grid_sample

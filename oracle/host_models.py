@@ -4,6 +4,7 @@ reference's golden flows) and by bench.py's ``cpu_baseline`` leg.  TEST INFRASTR
 substitution is made from here, the product never selects it."""
 import contextlib
 
+import torch
 import torch.nn as nn
 
 from . import ops as O
@@ -14,8 +15,9 @@ class OracleCorrelation(nn.Module):
         super().__init__()
         self.d = d
 
-    def forward(self, x1, x2):
-        return O.correlation(x1, x2, self.d)
+    def forward(self, x1, x2, negative_slope=1.0):
+        out = O.correlation(x1, x2, self.d)
+        return out if negative_slope == 1.0 else torch.nn.functional.leaky_relu(out, negative_slope)
 
 
 @contextlib.contextmanager
@@ -30,7 +32,8 @@ def oracle_ops(model):
     try:
         mp.flow_warp = O.flow_warp
         mpu.flow_warp = O.flow_warp
-        mum.compute_cost_volume = lambda a, b, max_displacement: O.correlation(a, b, max_displacement)
+        mum.compute_cost_volume = lambda a, b, max_displacement, negative_slope=1.0: OracleCorrelation(
+            max_displacement)(a, b, negative_slope)
         mum.uflow_utils.resample_flow = lambda src, flow: O.resample(src, O.flow_to_warp(flow))
         if old_corr is not None:
             model.corr = OracleCorrelation(4)

@@ -33,7 +33,7 @@ def cu(t):
 def test_library_loaded_and_no_fallback():
     from arflow_amd import _lib, functional
     lib = _lib.load()
-    assert lib.arflow_abi_version() == 1
+    assert lib.arflow_abi_version() == 2
     with pytest.raises(_lib.ArflowHipError):
         functional.correlation(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4))  # CPU tensor must raise
 
@@ -73,6 +73,25 @@ def test_correlation_vs_oracle(AF, oracle, shape):
     y2 = AF.correlation(a2, cu(x2), d)
     g1b, = torch.autograd.grad(y2, [a2], cu(go))
     assert_close(g1b, r1, 5e-6, 1e-5, 'corr gx1-only')
+
+
+def test_correlation_fused_leaky_relu(AF, oracle):
+    """corr + LeakyReLU(0.1) fused in the kernel == leaky_relu(oracle corr), forward and both gradients."""
+    gen = torch.Generator().manual_seed(77)
+    for B, C, H, W in ((2, 32, 24, 40), (1, 5, 9, 11)):
+        x1 = torch.randn(B, C, H, W, generator=gen)
+        x2 = torch.randn(B, C, H, W, generator=gen)
+        go = torch.randn(B, 81, H, W, generator=gen)
+        a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        ref = torch.nn.functional.leaky_relu(oracle.correlation(a, b, 4), 0.1)
+        r1, r2 = torch.autograd.grad(ref, [a, b], go)
+        ac, bc = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
+        y = AF.correlation(ac, bc, 4, negative_slope=0.1)
+        assert_close(y, ref, 1e-6, 1e-5, 'fused leaky fwd')
+        g1, g2 = torch.autograd.grad(y, [ac, bc], cu(go))
+        # a pre-activation within rounding of 0 may pick the other branch: compare away from it
+        assert_close(g1, r1, 1e-5, 1e-4, 'fused leaky gx1')
+        assert_close(g2, r2, 1e-5, 1e-4, 'fused leaky gx2')
 
 
 def test_correlation_module_signature(AF):

@@ -75,9 +75,9 @@ def main():
         wout = torch.empty_like(x1)
         gfl = torch.empty_like(fl)
         if want('corr_fwd'):
-            rec('arflow_corr_fwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_fwd(p(x1), p(x2), p(out), B2, C, h, w, 4, s), args.iters))
+            rec('arflow_corr_fwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_fwd(p(x1), p(x2), p(out), B2, C, h, w, 4, 0.1, s), args.iters))
         if want('corr_bwd'):
-            rec('arflow_corr_bwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_bwd(p(go), p(x1), p(x2), p(g1), p(g2), B2, C, h, w, 4, s), args.iters))
+            rec('arflow_corr_bwd', (B2, C, h, w, 4, True), timeit(lambda: lib.arflow_corr_bwd(p(go), p(out), p(x1), p(x2), p(g1), p(g2), B2, C, h, w, 4, 0.1, s), args.iters))
         if want('warp_fwd'):
             rec('arflow_warp_fwd', (B2, C, h, w), timeit(lambda: lib.arflow_warp_fwd(p(x2), p(fl), p(wout), None, B2, C, h, w, h, w, 2 * h * w, 0, 1, 0, s), args.iters))
         if want('warp_bwd'):
