@@ -20,10 +20,13 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    def __init__(self, module, n_buckets=4, process_group=None):
+    def __init__(self, module, n_buckets=4, process_group=None, force_collectives=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # force_collectives: run the bucket all-reduces even at world size 1 (exercises the RCCL path on a
+        # one-GPU box; a 1-rank all-reduce is the identity)
+        self._active = self.world > 1 or (force_collectives and dist.is_available() and dist.is_initialized())
         params = [p for p in module.parameters() if p.requires_grad]
         assert params, 'no trainable parameters'
         dev, dt = params[0].device, params[0].dtype
@@ -54,11 +57,11 @@ class FlatGradAllReduce:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        if self._active:
             for bi, (_, _, members) in enumerate(self.buckets):
                 for p in members:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
-        self._use_avg = self.world > 1 and dist.get_backend(process_group) == 'nccl'
+        self._use_avg = self._active and dist.get_backend(process_group) == 'nccl'
         self.reset()
 
     def _make_hook(self, bi):
@@ -85,7 +88,7 @@ class FlatGradAllReduce:
     def finish(self):
         """Wait for the bucket all-reduces launched during backward (and launch any whose parameters
         received no gradient this step), leaving the averaged gradient in ``param.grad``."""
-        if self.world == 1:
+        if not self._active:
             return
         for bi, (s, e, _) in enumerate(self.buckets):
             if self._pending[bi] != 0:  # some parameter got no gradient: reduce the bucket now
@@ -98,7 +101,7 @@ class FlatGradAllReduce:
         self.reset()
 
     def broadcast_parameters(self, src=0):
-        if self.world == 1:
+        if not self._active:
             return
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)

@@ -50,7 +50,9 @@ class TrainStep:
         if channels_last:  # experiment knob: NHWC activations for the MIOpen convolutions
             self.model.to(memory_format=torch.channels_last)
         self.loss = get_loss(self.loss_cfg)
-        self.reducer = FlatGradAllReduce(self.model, n_buckets=n_buckets)
+        import os
+        self.reducer = FlatGradAllReduce(self.model, n_buckets=n_buckets,
+                                         force_collectives=os.environ.get('ARFLOW_FORCE_COLLECTIVES') == '1')
         self.reducer.broadcast_parameters(0)
         # Adam, lr 1e-4, betas (0.9, 0.999), eps 1e-8, no decay: configs/chairs_uflow.json:29-48
         kw = dict(lr=lr, betas=(0.9, 0.999), eps=1e-8)

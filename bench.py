@@ -144,8 +144,12 @@ def main():
         sys.exit('bench.py needs a GPU: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('ARFLOW_FORCE_COLLECTIVES') == '1'
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend='nccl', device_id=device)
 
     from arflow_amd import functional as AF
@@ -159,7 +163,7 @@ def main():
     img = synthetic_pairs(args.batch, H, W, device=device, seed=100 + rank)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +181,7 @@ def main():
     finite = bool(torch.isfinite(step.last).item())
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -221,7 +225,7 @@ def main():
             except Exception as e:  # never lose the GPU number because the baseline leg failed
                 line['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
