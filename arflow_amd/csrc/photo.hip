@@ -149,6 +149,199 @@ __global__ __launch_bounds__(TX* TY) void census_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Census, 4 pixels per lane (used when W % 4 == 0): tile 16 rows x 64 columns per 256-thread workgroup.
+//   * tiles are filled with aligned float4 global loads (3 planes -> grey in registers -> one float4 LDS
+//     store) instead of one bounds-checked dword per element;
+//   * a lane reads each of the 2R+1 window rows as three ds_read_b128 (12 floats starting 4 columns left
+//     of its pixel group) and reuses them for its 4 pixels: 9x fewer LDS instructions than one b32 per
+//     (pixel, neighbour), and 4 independent accumulation chains per lane;
+//   * row pitch 128 floats (a multiple of the 64-bank row) keeps those b128 reads conflict-free for the
+//     lane -> (pixel group = lane % 16, row = lane / 16) map.
+// ------------------------------------------------------------------------------------------------
+namespace census4 {
+constexpr int TXW = 64, TYH = 16, NT = 256, PITCH = 128, MAXR = 3;
+constexpr int ROWS = TYH + 2 * MAXR;  // 22 tile rows (R = 3); smaller radii use the top-left part
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// grey tile covering image rows [ty0-R, ty0+TYH+R) and columns [tx0-4, tx0+TXW+4), zero outside
+template <int R>
+__device__ __forceinline__ void load_gray(float* __restrict__ tile, const float* __restrict__ im, int H, int W,
+                                          int ty0, int tx0) {
+  constexpr int NR = TYH + 2 * R, NQ = (TXW + 8) / 4;  // 18 float4 per row
+  const long cs = (long)H * W;
+  for (int i = threadIdx.x; i < NR * NQ; i += NT) {
+    const int r = i / NQ, q = i - r * NQ;
+    const int gy = ty0 - R + r, gx = tx0 - 4 + 4 * q;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const float* p = im + (long)gy * W + gx;
+      const float4 a = *reinterpret_cast<const float4*>(p);
+      const float4 b = *reinterpret_cast<const float4*>(p + cs);
+      const float4 c = *reinterpret_cast<const float4*>(p + 2 * cs);
+      g.x = ((a.x * 0.2989f + b.x * 0.5870f) + c.x * 0.1140f) * 255.f;
+      g.y = ((a.y * 0.2989f + b.y * 0.5870f) + c.y * 0.1140f) * 255.f;
+      g.z = ((a.z * 0.2989f + b.z * 0.5870f) + c.z * 0.1140f) * 255.f;
+      g.w = ((a.w * 0.2989f + b.w * 0.5870f) + c.w * 0.1140f) * 255.f;
+    }
+    *reinterpret_cast<float4*>(tile + r * PITCH + 4 * q) = g;
+  }
+}
+
+__device__ __forceinline__ void read12(const float* row, float (&w)[12]) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * q);
+    asm volatile("" : "+v"(t));  // keep it one ds_read_b128
+    w[4 * q] = t.x, w[4 * q + 1] = t.y, w[4 * q + 2] = t.z, w[4 * q + 3] = t.w;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ im_a, const float* __restrict__ im_b,
+                                                 const float* __restrict__ mask, float* __restrict__ ham_out,
+                                                 float* __restrict__ dham_out, float* __restrict__ sums, int nimg,
+                                                 int H, int W) {
+  __shared__ __attribute__((aligned(16))) float ga[ROWS * PITCH];
+  __shared__ __attribute__((aligned(16))) float gb[ROWS * PITCH];
+  __shared__ float red[2 * (NT / 64)];
+  int btx, bty, b;
+  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) return;
+  const int ty0 = bty * TYH, tx0 = btx * TXW;
+  const long ims = 3L * H * W;
+  load_gray<R>(ga, im_a + b * ims, H, W, ty0, tx0);
+  load_gray<R>(gb, im_b + b * ims, H, W, ty0, tx0);
+  __syncthreads();
+  const int xg = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int x0 = tx0 + 4 * xg, y = ty0 + ly;
+  // window row `dy` of this lane: tile row ly+dy, columns 4*xg .. 4*xg+11 (= image x0-4 .. x0+7)
+  float ca[4], cb[4], s[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    float wa[12], wb[12];
+    read12(ga + (ly + R) * PITCH + 4 * xg, wa);
+    read12(gb + (ly + R) * PITCH + 4 * xg, wb);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ca[p] = wa[4 + p], cb[p] = wb[4 + p];
+  }
+#pragma unroll 1
+  for (int dy = 0; dy <= 2 * R; ++dy) {
+    float wa[12], wb[12];
+    read12(ga + (ly + dy) * PITCH + 4 * xg, wa);
+    read12(gb + (ly + dy) * PITCH + 4 * xg, wb);
+#pragma unroll
+    for (int dx = 0; dx <= 2 * R; ++dx)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int k = p + dx + 4 - R;  // neighbour column x0+p+dx-R  <->  window index (x0+p+dx-R) - (x0-4)
+        const float da = wa[k] - ca[p], db = wb[k] - cb[p];
+        const float ta = da * __builtin_amdgcn_rsqf(fmaf(da, da, 0.81f));
+        const float tb = db * __builtin_amdgcn_rsqf(fmaf(db, db, 0.81f));
+        const float e = ta - tb, sq = e * e;
+        s[p] = fmaf(sq, __builtin_amdgcn_rcpf(0.1f + sq), s[p]);
+      }
+  }
+  float part[2] = {0.f, 0.f};
+  if (y < H && x0 < W) {  // W % 4 == 0: the 4 pixels are inside together
+    const long o = ((long)b * H + y) * W + x0;
+    if (ham_out) *reinterpret_cast<float4*>(ham_out + o) = make_float4(s[0], s[1], s[2], s[3]);
+    if (mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+      const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
+      float dh[4];
+      const bool rowin = y >= R && y < H - R;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int xx = x0 + p;
+        const float pm = (rowin && xx >= R && xx < W - R) ? mv[p] : 0.f;
+        const float lg = __log2f(fabsf(s[p]) + 0.01f);
+        part[0] += exp2f(0.4f * lg) * pm;
+        part[1] += pm;
+        dh[p] = pm * 0.4f * exp2f(-0.6f * lg);
+      }
+      if (dham_out) *reinterpret_cast<float4*>(dham_out + o) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+    }
+  }
+  if (mask) {
+    af_block_sum<2>(part, red);
+    if (threadIdx.x == 0) {
+      float* slot = af_sum_slot(sums);
+      atomicAdd(slot, part[0]);
+      atomicAdd(slot + 1, part[1]);
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ im_a, const float* __restrict__ im_b,
+                                                 const float* __restrict__ gham, const float* __restrict__ scale,
+                                                 float* __restrict__ g_im_b, int nimg, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float ga[ROWS * PITCH];
+  __shared__ __attribute__((aligned(16))) float gb[ROWS * PITCH];
+  __shared__ __attribute__((aligned(16))) float gg[ROWS * PITCH];
+  int btx, bty, b;
+  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) return;
+  const int ty0 = bty * TYH, tx0 = btx * TXW;
+  const long ims = 3L * H * W;
+  load_gray<R>(ga, im_a + b * ims, H, W, ty0, tx0);
+  load_gray<R>(gb, im_b + b * ims, H, W, ty0, tx0);
+  {
+    constexpr int NR = TYH + 2 * R, NQ = (TXW + 8) / 4;
+    const float* g = gham + (long)b * H * W;
+    for (int i = threadIdx.x; i < NR * NQ; i += NT) {
+      const int r = i / NQ, q = i - r * NQ;
+      const int gy = ty0 - R + r, gx = tx0 - 4 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(g + (long)gy * W + gx);
+      *reinterpret_cast<float4*>(gg + r * PITCH + 4 * q) = v;
+    }
+  }
+  __syncthreads();
+  const int xg = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int x0 = tx0 + 4 * xg, y = ty0 + ly;
+  if (y >= H || x0 >= W) return;
+  float ca[4], cb[4], cg[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    float wa[12], wb[12], wg[12];
+    read12(ga + (ly + R) * PITCH + 4 * xg, wa);
+    read12(gb + (ly + R) * PITCH + 4 * xg, wb);
+    read12(gg + (ly + R) * PITCH + 4 * xg, wg);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ca[p] = wa[4 + p], cb[p] = wb[4 + p], cg[p] = wg[4 + p];
+  }
+#pragma unroll 1
+  for (int dy = 0; dy <= 2 * R; ++dy) {
+    float wa[12], wb[12], wg[12];
+    read12(ga + (ly + dy) * PITCH + 4 * xg, wa);
+    read12(gb + (ly + dy) * PITCH + 4 * xg, wb);
+    read12(gg + (ly + dy) * PITCH + 4 * xg, wg);
+#pragma unroll
+    for (int dx = 0; dx <= 2 * R; ++dx) {
+      if (dy == R && dx == R) continue;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int k = p + dx + 4 - R;  // tile pixel r - kk, kk = (R-dy, R-dx)
+        const float da = ca[p] - wa[k], db = cb[p] - wb[k];
+        const float ua = __builtin_amdgcn_rsqf(fmaf(da, da, 0.81f));
+        const float ub = __builtin_amdgcn_rsqf(fmaf(db, db, 0.81f));
+        const float e = da * ua - db * ub, sq = e * e;
+        const float q = __builtin_amdgcn_rcpf(0.1f + sq);
+        const float hd = (0.1f * q * q) * (-2.f * e) * (0.81f * ub * ub * ub);
+        acc[p] = fmaf(wg[k] + cg[p], hd, acc[p]);
+      }
+    }
+  }
+  const float sc = (scale ? scale[0] : 1.f) * 255.f;
+  float* o = g_im_b + b * ims + (long)y * W + x0;
+  const long cs = (long)H * W;
+  *reinterpret_cast<float4*>(o) =
+      make_float4(sc * acc[0] * 0.2989f, sc * acc[1] * 0.2989f, sc * acc[2] * 0.2989f, sc * acc[3] * 0.2989f);
+  *reinterpret_cast<float4*>(o + cs) =
+      make_float4(sc * acc[0] * 0.5870f, sc * acc[1] * 0.5870f, sc * acc[2] * 0.5870f, sc * acc[3] * 0.5870f);
+  *reinterpret_cast<float4*>(o + 2 * cs) =
+      make_float4(sc * acc[0] * 0.1140f, sc * acc[1] * 0.1140f, sc * acc[2] * 0.1140f, sc * acc[3] * 0.1140f);
+}
+}  // namespace census4
+
+// ------------------------------------------------------------------------------------------------
 // SSIM (3x3, un-padded) + L1
 // ------------------------------------------------------------------------------------------------
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
@@ -336,6 +529,16 @@ extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const flo
     hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
     if (e != hipSuccess) return af_hip_status(e);
   }
+  if ((W & 3) == 0) {
+    namespace c4 = census4;
+    dim3 g4(af_grid_for_tiles((long)af_cdiv(W, c4::TXW) * af_cdiv(H, c4::TYH) * B));
+    switch (radius) {
+      case 1: hipLaunchKernelGGL(c4::fwd_kernel<1>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
+      case 2: hipLaunchKernelGGL(c4::fwd_kernel<2>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
+      default: hipLaunchKernelGGL(c4::fwd_kernel<3>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
+    }
+    return af_launch_status();
+  }
   dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
   switch (radius) {
     case 1: hipLaunchKernelGGL(census_fwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
@@ -354,6 +557,16 @@ extern "C" int arflow_census_bwd(const float* im_a, const float* im_b, const flo
   AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 8 * 65535, ARFLOW_ESHAPE);
   AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
+  if ((W & 3) == 0) {
+    namespace c4 = census4;
+    dim3 g4(af_grid_for_tiles((long)af_cdiv(W, c4::TXW) * af_cdiv(H, c4::TYH) * B));
+    switch (radius) {
+      case 1: hipLaunchKernelGGL(c4::bwd_kernel<1>, g4, dim3(c4::NT), 0, st, im_a, im_b, gham, scale, g_im_b, B, H, W); break;
+      case 2: hipLaunchKernelGGL(c4::bwd_kernel<2>, g4, dim3(c4::NT), 0, st, im_a, im_b, gham, scale, g_im_b, B, H, W); break;
+      default: hipLaunchKernelGGL(c4::bwd_kernel<3>, g4, dim3(c4::NT), 0, st, im_a, im_b, gham, scale, g_im_b, B, H, W); break;
+    }
+    return af_launch_status();
+  }
   dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
   switch (radius) {
     case 1: hipLaunchKernelGGL(census_bwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, gham, scale, g_im_b, B, H, W); break;
