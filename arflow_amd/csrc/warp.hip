@@ -212,106 +212,11 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
   }
 }
 
-// gsrc: 4-tap atomic scatter (pre-zeroed); gflow: per-pixel reduction over channels.
-template <bool WITH_SRC, bool WITH_FLOW>
-__global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ gout,
-                                                       const float* __restrict__ src,
-                                                       const float* __restrict__ flow,
-                                                       float* __restrict__ gsrc, float* __restrict__ gflow,
-                                                       int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
-                                                       int pad, int align, int norm) {
-  int btx, bty, b;
-  if (!af_tile_of_block((W + 31) / 32, (H + 7) / 8, nimg, btx, bty, b)) return;
-  const int x = btx * 32 + (int)(threadIdx.x & 31), y = bty * 8 + (int)(threadIdx.x >> 5);
-  if (x >= W || y >= H) return;
-  const float* fb = flow + (long)b * fbs + (long)y * W + x;
-  const Taps t = make_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
-  const float wnw = t.wx0 * t.wy0, wne = t.wx1 * t.wy0, wsw = t.wx0 * t.wy1, wse = t.wx1 * t.wy1;
-  const bool bnw = t.vx0 && t.vy0, bne = t.vx1 && t.vy0, bsw = t.vx0 && t.vy1, bse = t.vx1 && t.vy1;
-  const long o00 = (long)t.y0 * Ws + t.x0;
-  const long ss = (long)Hs * Ws, os = (long)H * W;
-  const float* sp = src + (long)b * C * ss;
-  float* gp = WITH_SRC ? gsrc + (long)b * C * ss : nullptr;
-  const float* gop = gout + (long)b * C * os + (long)y * W + x;
-  float gix = 0.f, giy = 0.f;
-  const TapPlan tp = plan_taps(t, Hs, Ws);
-#pragma unroll 4
-  for (int c = 0; c < C; ++c) {
-    const float g = gop[c * os];
-    if (WITH_SRC) {
-      float* d = gp + c * ss + o00;
-      if (bnw) atomicAdd(d, g * wnw);
-      if (bne) atomicAdd(d + 1, g * wne);
-      if (bsw) atomicAdd(d + Ws, g * wsw);
-      if (bse) atomicAdd(d + Ws + 1, g * wse);
-    }
-    if (WITH_FLOW) {
-      const float* s = sp + c * ss;
-      float a0 = s[tp.o[0]], a1 = s[tp.o[1]], a2 = s[tp.o[2]], a3 = s[tp.o[3]];
-      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
-      const float nw = bnw ? a0 : 0.f, ne = bne ? a1 : 0.f;
-      const float sw = bsw ? a2 : 0.f, se = bse ? a3 : 0.f;
-      // d out / d ix = (ne-nw)*wy0 + (se-sw)*wy1 ; d out / d iy = (sw-nw)*wx0 + (se-ne)*wx1
-      gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
-      giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
-    }
-  }
-  if (WITH_FLOW) {
-    float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
-    gf[0] = gix * t.dx;
-    gf[os] = giy * t.dy;
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// warp backward with the scatter turned into a gather through an index list built in LDS.
-//
-// One workgroup = an 8 x 32 tile of output pixels.  The four bilinear taps of its pixels land in a
-// small source window (flow fields are piecewise smooth) whose geometry does not depend on the
-// channel.  So, ONCE per tile, the workgroup builds a CSR list "window cell -> (pixel, weight)
-// contributors" with INTEGER LDS atomics (ds_add_u32: ~8 cycles per wave instruction; the float form
-// ds_add_f32 measured ~200 cycles on gfx950 and made a direct LDS-atomic accumulation 4x slower than
-// the whole rest of the kernel).  Then, per chunk of CCH channels, every thread stages its gout
-// values in LDS and each window cell sums its contributors with plain fp32 FMAs and issues ONE global
-// atomic per touched cell and channel: 64 lanes on 64 consecutive addresses, no same-address
-// collisions inside an instruction (those made the direct 4-taps-per-pixel scatter 5-8x slower on
-// displaced fields), ~2.2x fewer atomics.  A window that does not fit (WMAX x HMAX: a violently
-// divergent field) falls back to direct global atomics for that tile.
-// ------------------------------------------------------------------------------------------------
-namespace lds_scatter {
-constexpr int TX = 32, TY = 8, NT = TX * TY;
-constexpr int WMAX = 64, HMAX = 24, NCELL = WMAX * HMAX, CCH = 4;
-
-template <bool WITH_FLOW>
-__global__ __launch_bounds__(NT) void warp_bwd_lds_kernel(const float* __restrict__ gout,
-                                                          const float* __restrict__ src,
-                                                          const float* __restrict__ flow,
-                                                          float* __restrict__ gsrc, float* __restrict__ gflow,
-                                                          int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
-                                                          int pad, int align, int norm) {
-  __shared__ int cell_beg[NCELL + 1];  // CSR row starts (after the scan)
-  __shared__ int cell_end[NCELL];      // counts, then running fill pointers = row ends
-  __shared__ float2 entry[4 * NT];     // (pixel index as float bits, weight)
-  __shared__ float gt[2][CCH][NT];     // staged output gradients, double-buffered
-  __shared__ int red[4][NT / 64];
-  __shared__ int box[4];
-  __shared__ int wave_tot[NT / 64];
-  const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
-  int btx, bty, b;
-  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b)) return;  // whole workgroup
-  const int x = btx * TX + lx, y = bty * TY + ly;
-  const bool inside = x < W && y < H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  Taps t;
-  if (inside) {
-    const float* fb = flow + (long)b * fbs + (long)y * W + x;
-    t = make_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
-  } else {
-    t.vx0 = t.vx1 = t.vy0 = t.vy1 = false;
-    t.x0 = t.y0 = 0;
-    t.wx0 = t.wx1 = t.wy0 = t.wy1 = t.dx = t.dy = 0.f;
-  }
+// Shared prologue of the tile kernels: bounding box of the valid taps of the workgroup's 256 pixels.
+struct TileBox {
+  int x0, y0, x1, y1;  // inclusive; empty when x1 < x0
+};
+__device__ __forceinline__ TileBox tile_bbox(const Taps& t, int (*red)[4], int* box) {
   const bool any = (t.vx0 || t.vx1) && (t.vy0 || t.vy1);
   int lo_x = any ? t.x0 + (t.vx0 ? 0 : 1) : 0x7fffffff, hi_x = any ? t.x0 + (t.vx1 ? 1 : 0) : -0x7fffffff;
   int lo_y = any ? t.y0 + (t.vy0 ? 0 : 1) : 0x7fffffff, hi_y = any ? t.y0 + (t.vy1 ? 1 : 0) : -0x7fffffff;
@@ -322,135 +227,280 @@ __global__ __launch_bounds__(NT) void warp_bwd_lds_kernel(const float* __restric
     hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
     hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) red[0][wave] = lo_x, red[1][wave] = lo_y, red[2][wave] = hi_x, red[3][wave] = hi_y;
-  for (int i = threadIdx.x; i < NCELL; i += NT) cell_end[i] = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     int a = red[0][0], bb = red[1][0], c = red[2][0], d = red[3][0];
-    for (int w = 1; w < NT / 64; ++w)
-      a = min(a, red[0][w]), bb = min(bb, red[1][w]), c = max(c, red[2][w]), d = max(d, red[3][w]);
+    for (int w = 1; w < 4; ++w) a = min(a, red[0][w]), bb = min(bb, red[1][w]), c = max(c, red[2][w]), d = max(d, red[3][w]);
     box[0] = a, box[1] = bb, box[2] = c, box[3] = d;
   }
   __syncthreads();
-  const int bx0 = box[0], by0 = box[1];
-  const int bw = box[2] - bx0 + 1, bh = box[3] - by0 + 1;
-  const bool empty = box[2] < bx0;
-  const bool priv = !empty && bw <= WMAX && bh <= HMAX;
+  TileBox r;
+  r.x0 = box[0], r.y0 = box[1], r.x1 = box[2], r.y1 = box[3];
+  return r;
+}
+__device__ __forceinline__ Taps no_taps() {
+  Taps t;
+  t.vx0 = t.vx1 = t.vy0 = t.vy1 = false;
+  t.x0 = t.y0 = 0;
+  t.wx0 = t.wx1 = t.wy0 = t.wy1 = t.dx = t.dy = 0.f;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// d loss / d flow of the warp: per pixel  sum_c gout_c * (bilinear corner differences of src_c), times
+// d coord / d flow.  Same tile / LDS source-window structure as the forward kernel; this is the whole
+// backward of the loss-side image warps (their source is detached, losses/uflow_loss.py:31,34).
+// ------------------------------------------------------------------------------------------------
+namespace flow_grad {
+using fwd_win::CCH;
+using fwd_win::HMAX;
+template <int WQ>
+__device__ __forceinline__ void run(float* __restrict__ win, const float* __restrict__ sp,
+                                    const float* __restrict__ gop, const TapPlan& p, const Taps& t, bool inside, int C,
+                                    int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
+                                    float& gix, float& giy) {
+  constexpr int WP = 4 * WQ;
+  for (int c0 = 0; c0 < C; c0 += CCH) {
+    const int per = bh * WQ;
+    float g[CCH];
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) g[c] = (inside && c0 + c < C) ? gop[(long)(c0 + c) * os] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) {
+      if (c0 + c < C) {
+        const float* s = sp + (long)(c0 + c) * ss + (long)by0 * Ws + ax0;
+        for (int i = threadIdx.x; i < per; i += 256) {
+          const int r = i / WQ, xs = i - r * WQ;
+          if (ax0 + 4 * xs < Ws)
+            *reinterpret_cast<float4*>(win + (c * HMAX + r) * WP + 4 * xs) =
+                *reinterpret_cast<const float4*>(s + (long)r * Ws + 4 * xs);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) {
+      const float* w = win + c * HMAX * WP;
+      const float nw = p.ok[0] ? w[l0] : 0.f, ne = p.ok[1] ? w[l1] : 0.f;
+      const float sw = p.ok[2] ? w[l2] : 0.f, se = p.ok[3] ? w[l3] : 0.f;
+      gix = fmaf(g[c], (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
+      giy = fmaf(g[c], (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
+    }
+    __syncthreads();
+  }
+}
+}  // namespace flow_grad
+
+__global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restrict__ gout,
+                                                            const float* __restrict__ src,
+                                                            const float* __restrict__ flow, float* __restrict__ gflow,
+                                                            int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
+                                                            int pad, int align, int norm) {
+  using namespace fwd_win;
+  __shared__ __attribute__((aligned(16))) float win[CCH * HMAX * 72];
+  __shared__ int red[4][4];
+  __shared__ int box[4];
+  int btx, bty, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b)) return;
+  const int x = btx * TX + (int)(threadIdx.x & 31), y = bty * TY + (int)(threadIdx.x >> 5);
+  const bool inside = x < W && y < H;
+  Taps t = no_taps();
+  if (inside) {
+    const float* fb = flow + (long)b * fbs + (long)y * W + x;
+    t = make_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
+  }
+  const TapPlan p = plan_taps(t, Hs, Ws);
+  const TileBox bb = tile_bbox(t, red, box);
+  const int bh = bb.y1 - bb.y0 + 1, ax0 = bb.x0 & ~3, aw = bb.x1 - ax0 + 1;
+  const bool empty = bb.x1 < bb.x0;
+  const int ss = Hs * Ws, os = H * W;
+  const float* sp = src + (long)b * C * ss;
+  const float* gop = gout + (long)b * C * os + (long)y * W + x;
+  float gix = 0.f, giy = 0.f;
+  if (!empty && (Ws & 3) == 0 && bh <= HMAX && aw <= 72) {
+    const int xa = min(max(t.x0, 0), Ws - 1) - ax0, xb = min(max(t.x0 + 1, 0), Ws - 1) - ax0;
+    const int ya = min(max(t.y0, 0), Hs - 1) - bb.y0, yb = min(max(t.y0 + 1, 0), Hs - 1) - bb.y0;
+    const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
+    const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
+    if (aw <= 48)
+      flow_grad::run<12>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa, cya * 48 + cxb,
+                         cyb * 48 + cxa, cyb * 48 + cxb, gix, giy);
+    else
+      flow_grad::run<18>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa, cya * 72 + cxb,
+                         cyb * 72 + cxa, cyb * 72 + cxb, gix, giy);
+  } else if (inside && !empty) {
+    for (int c = 0; c < C; ++c) {  // direct gathers (window too large or unaligned rows)
+      const float g = gop[(long)c * os];
+      const float* s = sp + (long)c * ss;
+      float a0 = s[p.o[0]], a1 = s[p.o[1]], a2 = s[p.o[2]], a3 = s[p.o[3]];
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      const float nw = p.ok[0] ? a0 : 0.f, ne = p.ok[1] ? a1 : 0.f, sw = p.ok[2] ? a2 : 0.f, se = p.ok[3] ? a3 : 0.f;
+      gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
+      giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
+    }
+  }
+  if (inside) {
+    float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
+    gf[0] = gix * t.dx;
+    gf[os] = giy * t.dy;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// d loss / d src of the warp: the 4-tap scatter turned into a gather through an index list in LDS.
+//
+// One workgroup = an 8 x 32 tile of output pixels.  The taps of its pixels land in a source window whose
+// geometry does not depend on the channel.  So, ONCE per tile, the workgroup builds a CSR list
+// "window cell -> (pixel, weight) contributors" with INTEGER LDS atomics (ds_add_u32: ~8 cycles per
+// wave instruction; the float form ds_add_f32 measured ~200 cycles on gfx950, tools/ubench) and compacts
+// the non-empty cells.  Then, per chunk of CCH channels, every thread stages its gout values in LDS and
+// each non-empty cell sums its contributors with plain fp32 FMAs and issues ONE global atomic per cell
+// and channel -- consecutive lanes on consecutive addresses, no same-address collisions inside an
+// instruction (those made the direct 4-taps-per-pixel scatter 5-8x slower on displaced fields), ~2x
+// fewer atomics.  The window may be as large as 128 x 64 (a violently divergent field); beyond that the
+// tile falls back to direct global atomics.
+// ------------------------------------------------------------------------------------------------
+namespace lds_scatter {
+constexpr int TX = 32, TY = 8, NT = TX * TY;
+constexpr int WMAX = 128, HMAX = 64, NCELL = WMAX * HMAX, CCH = 4;
+
+__global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restrict__ gout,
+                                                          const float* __restrict__ flow, float* __restrict__ gsrc,
+                                                          int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
+                                                          int pad, int align, int norm) {
+  // cell c lives at cell_ptr[c + (c >> 5)]: the scan walks a lane-private run of consecutive cells, and the
+  // +1-per-32 skew keeps 64 lanes with a stride that is a multiple of 32 on distinct banks
+  __shared__ int cell_ptr[NCELL + NCELL / 32 + 1];  // counts, then running fill pointers
+  __shared__ unsigned short ne_cell[4 * NT];    // compacted non-empty cells, packed (row << 7 | col), row-major
+  __shared__ unsigned short ne_beg[4 * NT + 1]; // first entry of each non-empty cell; [n] = total
+  __shared__ float2 entry[4 * NT];              // (pixel index as float bits, weight)
+  __shared__ float gt[2][CCH][NT];              // staged output gradients, double-buffered
+  __shared__ int red[4][4];
+  __shared__ int box[4];
+  __shared__ int wave_tot[2][NT / 64];
+  const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
+  int btx, bty, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b)) return;  // whole workgroup
+  const int x = btx * TX + lx, y = bty * TY + ly;
+  const bool inside = x < W && y < H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Taps t = no_taps();
+  if (inside) {
+    const float* fb = flow + (long)b * fbs + (long)y * W + x;
+    t = make_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
+  }
+  const TileBox bb = tile_bbox(t, red, box);
+  const int bx0 = bb.x0, by0 = bb.y0;
+  const int bw = bb.x1 - bx0 + 1, bh = bb.y1 - by0 + 1;
+  const bool empty = bb.x1 < bx0;
+  if (empty) return;  // no pixel of the tile samples inside the source: nothing to add (uniform)
+  const bool priv = bw <= WMAX && bh <= HMAX;
 
   const float wgt[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
   const bool ok[4] = {t.vx0 && t.vy0, t.vx1 && t.vy0, t.vx0 && t.vy1, t.vx1 && t.vy1};
   const long o00 = (long)t.y0 * Ws + t.x0;
   const long ss = (long)Hs * Ws, os = (long)H * W;
-  const float* sp = src + (long)b * C * ss;
   float* gp = gsrc + (long)b * C * ss;
   const float* gop = gout + (long)b * C * os + (long)y * W + x;
-  float gix = 0.f, giy = 0.f;
 
-  const TapPlan tp = plan_taps(t, Hs, Ws);
-  auto flow_terms = [&](int c, float g) {
-    const float* s = sp + c * ss;
-    float a0 = s[tp.o[0]], a1 = s[tp.o[1]], a2 = s[tp.o[2]], a3 = s[tp.o[3]];
-    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
-    const float nw = ok[0] ? a0 : 0.f, ne = ok[1] ? a1 : 0.f;
-    const float sw = ok[2] ? a2 : 0.f, se = ok[3] ? a3 : 0.f;
-    gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
-    giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
-  };
-
-  if (priv) {
-    const int rx = t.x0 - bx0, ry = t.y0 - by0;
-    const int cell[4] = {ry * WMAX + rx, ry * WMAX + rx + 1, (ry + 1) * WMAX + rx, (ry + 1) * WMAX + rx + 1};
-    // 1. count contributors per cell
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (ok[k]) atomicAdd(&cell_end[cell[k]], 1);
-    __syncthreads();
-    // 2. exclusive scan of the counts over the bh * WMAX cells in use (6 consecutive cells per thread)
-    constexpr int PER = NCELL / NT;
-    int cnt[PER], run = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      cnt[i] = cell_end[threadIdx.x * PER + i];
-      run += cnt[i];
-    }
-    int incl = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int base = incl - run;
-    for (int w = 0; w < wave; ++w) base += wave_tot[w];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      cell_beg[threadIdx.x * PER + i] = base;
-      cell_end[threadIdx.x * PER + i] = base;  // becomes the fill pointer
-      base += cnt[i];
-    }
-    __syncthreads();
-    // 3. fill the lists
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (ok[k]) {
-        const int slot = atomicAdd(&cell_end[cell[k]], 1);
-        entry[slot] = make_float2(__int_as_float((int)threadIdx.x), wgt[k]);
+  if (!priv) {
+    if (inside)
+      for (int c = 0; c < C; ++c) {
+        const float g = gop[c * os];
+        float* d = gp + c * ss + o00;
+        if (ok[0]) atomicAdd(d, g * wgt[0]);
+        if (ok[1]) atomicAdd(d + 1, g * wgt[1]);
+        if (ok[2]) atomicAdd(d + Ws, g * wgt[2]);
+        if (ok[3]) atomicAdd(d + Ws + 1, g * wgt[3]);
       }
-    __syncthreads();
-    // 4. per channel chunk: stage gout, gather per cell, one global atomic per touched cell
-    const int fr0 = wave;  // cell (r, lane) with r = fr0, fr0 + 4, ...
-    int buf = 0;
-    for (int c0 = 0; c0 < C; c0 += CCH, buf ^= 1) {
+    return;
+  }
+  // window pitch: the box width rounded up to 32; only bh * wp cells are zeroed / scanned
+  const int wp = (bw + 31) & ~31;
+  const int ncell = bh * wp;
+  const int per = (ncell + NT - 1) / NT;  // consecutive cells owned by one thread in the scan
+  auto slot_of = [](int c) { return c + (c >> 5); };
+  for (int i = threadIdx.x; i < ncell + (ncell >> 5) + 1; i += NT) cell_ptr[i] = 0;
+  __syncthreads();
+  const int rx = t.x0 - bx0, ry = t.y0 - by0;
+  const int cell[4] = {ry * wp + rx, ry * wp + rx + 1, (ry + 1) * wp + rx, (ry + 1) * wp + rx + 1};
+  // 1. count contributors per cell
 #pragma unroll
-      for (int c = 0; c < CCH; ++c) {
-        float g = 0.f;
-        if (c0 + c < C && inside) {
-          g = gop[(c0 + c) * os];
-          if (WITH_FLOW) flow_terms(c0 + c, g);
-        }
-        gt[buf][c][threadIdx.x] = g;
+  for (int k = 0; k < 4; ++k)
+    if (ok[k]) atomicAdd(&cell_ptr[slot_of(cell[k])], 1);
+  __syncthreads();
+  // 2. scan: entries and non-empty cells are numbered in cell order
+  const int c_lo = min((int)threadIdx.x * per, ncell), c_hi = min(c_lo + per, ncell);
+  int run = 0, nz = 0;
+  for (int ci = c_lo; ci < c_hi; ++ci) {
+    const int c = cell_ptr[slot_of(ci)];
+    run += c;
+    nz += c != 0;
+  }
+  int incl = run, incz = nz;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64), z = __shfl_up(incz, off, 64);
+    if (lane >= off) incl += v, incz += z;
+  }
+  if (lane == 63) wave_tot[0][wave] = incl, wave_tot[1][wave] = incz;
+  __syncthreads();
+  int base = incl - run, basez = incz - nz, total = 0, totalz = 0;
+  for (int w = 0; w < NT / 64; ++w) {
+    if (w < wave) base += wave_tot[0][w], basez += wave_tot[1][w];
+    total += wave_tot[0][w], totalz += wave_tot[1][w];
+  }
+  {
+    int r = c_lo / wp, cc = c_lo - r * wp;  // running (row, col) of the cell
+    for (int ci = c_lo; ci < c_hi; ++ci) {
+      const int c = cell_ptr[slot_of(ci)];
+      if (c != 0) {
+        ne_cell[basez] = (unsigned short)((r << 7) | cc);
+        ne_beg[basez] = (unsigned short)base;
+        ++basez;
       }
-      __syncthreads();
-      if (lane < bw) {
-        for (int r = fr0; r < bh; r += NT / 64) {
-          const int ci = r * WMAX + lane;
-          const int beg = cell_beg[ci], end = cell_end[ci];
-          if (end > beg) {
-            float acc[CCH];
-#pragma unroll
-            for (int c = 0; c < CCH; ++c) acc[c] = 0.f;
-            for (int e = beg; e < end; ++e) {
-              const float2 en = entry[e];
-              const int pix = __float_as_int(en.x);
-#pragma unroll
-              for (int c = 0; c < CCH; ++c) acc[c] = fmaf(gt[buf][c][pix], en.y, acc[c]);
-            }
-            float* d = gp + (long)c0 * ss + (long)(by0 + r) * Ws + bx0 + lane;
-#pragma unroll
-            for (int c = 0; c < CCH; ++c)
-              if (c0 + c < C) atomicAdd(d + c * ss, acc[c]);
-          }
-        }
-      }
-      // gt is double-buffered: the next chunk's staging writes the other buffer, and the barrier after
-      // it orders this chunk's reads before the buffer is reused two chunks later
-    }
-  } else if (inside) {
-    for (int c = 0; c < C; ++c) {
-      const float g = gop[c * os];
-      float* d = gp + c * ss + o00;
-      if (ok[0]) atomicAdd(d, g * wgt[0]);
-      if (ok[1]) atomicAdd(d + 1, g * wgt[1]);
-      if (ok[2]) atomicAdd(d + Ws, g * wgt[2]);
-      if (ok[3]) atomicAdd(d + Ws + 1, g * wgt[3]);
-      if (WITH_FLOW) flow_terms(c, g);
+      cell_ptr[slot_of(ci)] = base;  // becomes the fill pointer
+      base += c;
+      if (++cc == wp) cc = 0, ++r;
     }
   }
-  if (WITH_FLOW && inside) {
-    float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
-    gf[0] = gix * t.dx;
-    gf[os] = giy * t.dy;
+  if (threadIdx.x == 0) ne_beg[totalz] = (unsigned short)total;
+  __syncthreads();
+  // 3. fill the lists
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (ok[k]) {
+      const int slot = atomicAdd(&cell_ptr[slot_of(cell[k])], 1);
+      entry[slot] = make_float2(__int_as_float((int)threadIdx.x), wgt[k]);
+    }
+  __syncthreads();
+  // 4. per channel chunk: stage gout, gather per non-empty cell, one global atomic per cell and channel
+  int buf = 0;
+  for (int c0 = 0; c0 < C; c0 += CCH, buf ^= 1) {
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) gt[buf][c][threadIdx.x] = (c0 + c < C && inside) ? gop[(c0 + c) * os] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < totalz; i += NT) {
+      const int ci = ne_cell[i];
+      const int beg = ne_beg[i], end = ne_beg[i + 1];
+      float acc[CCH];
+#pragma unroll
+      for (int c = 0; c < CCH; ++c) acc[c] = 0.f;
+      for (int e = beg; e < end; ++e) {
+        const float2 en = entry[e];
+        const int pix = __float_as_int(en.x);
+#pragma unroll
+        for (int c = 0; c < CCH; ++c) acc[c] = fmaf(gt[buf][c][pix], en.y, acc[c]);
+      }
+      float* d = gp + (long)c0 * ss + (long)(by0 + (ci >> 7)) * Ws + bx0 + (ci & 127);
+#pragma unroll
+      for (int c = 0; c < CCH; ++c)
+        if (c0 + c < C) atomicAdd(d + c * ss, acc[c]);
+    }
+    // gt is double-buffered: the next chunk stages into the other buffer; its barrier orders this chunk's
+    // reads before this buffer is overwritten two chunks later
   }
 }
 }  // namespace lds_scatter
@@ -581,20 +631,13 @@ extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float*
     hipError_t e = hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * C * Hs * Ws, st);
     if (e != hipSuccess) return af_hip_status(e);
   }
-  if (gsrc) {
-    namespace ls = lds_scatter;
-    const dim3 tgrid(af_grid_for_tiles((long)af_cdiv(W, ls::TX) * af_cdiv(H, ls::TY) * B));
-    if (gflow)
-      hipLaunchKernelGGL(ls::warp_bwd_lds_kernel<true>, tgrid, dim3(ls::NT), 0, st, gout, src, flow, gsrc, gflow, B, C,
-                         Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
-    else
-      hipLaunchKernelGGL(ls::warp_bwd_lds_kernel<false>, tgrid, dim3(ls::NT), 0, st, gout, src, flow, gsrc, gflow, B, C,
-                         Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
-  } else {
-    const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
-    hipLaunchKernelGGL((warp_bwd_kernel<false, true>), dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, gout, src,
-                       flow, gsrc, gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
-  }
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  if (gsrc)
+    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, gout, flow,
+                       gsrc, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  if (gflow)
+    hipLaunchKernelGGL(warp_bwd_flow_kernel, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, gout, src, flow, gflow, B,
+                       C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
   return af_launch_status();
 }
 
