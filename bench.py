@@ -75,6 +75,41 @@ def algorithmic_bytes(name, shape):
     return 0
 
 
+def pmc_traffic(name, shape):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of tools/kbench.py on the same shapes, gfx950 correction applied by
+    tools/make_traffic.py), or None when that launch shape was not profiled."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+
+    def cdiv(a, b):
+        return (a + b - 1) // b
+
+    def grid(tiles, threads):
+        return 8 * cdiv(tiles, 8) * threads
+
+    keys = []
+    if name in ('arflow_census_fwd', 'arflow_census_bwd'):
+        B, H, W = shape
+        keys = ['census4::%s_kernel<3>|%d' % (name[-3:], grid(cdiv(W, 64) * cdiv(H, 16) * B, 256))]
+    elif name in ('arflow_corr_fwd', 'arflow_corr_bwd'):
+        B, C, H, W = shape[:4]
+        tiles = cdiv(W, 32) * cdiv(H, 8) * B * (2 if name.endswith('bwd') else 1)
+        keys = ['corr_v2::%s_kernel<%d>|%d' % (name[-3:], 2 if tiles >= 768 else 4, grid(tiles, 192))]
+    elif name == 'arflow_warp_fwd':
+        B, C, H, W = shape
+        keys = ['warp_fwd_kernel|%d' % grid(cdiv(W, 32) * cdiv(H, 8) * B, 256)]
+    elif name == 'arflow_warp_bwd':
+        B, C, H, W, with_src = shape
+        g = grid(cdiv(W, 32) * cdiv(H, 8) * B, 256)
+        keys = ['warp_bwd_flow_kernel|%d' % g] + (['lds_scatter::warp_bwd_src_kernel|%d' % g] if with_src else [])
+    if not keys or any(k not in table for k in keys):
+        return None
+    return sum(table[k]['hbm_bytes'] for k in keys)
+
+
 def cpu_baseline(workload, height, width, budget_s=25.0):
     """The oracle (CPU restatement, kind 'port') on this host's cores: same workload shape, bounded
     sample (batch 1, a few steps).  Baseline only -- never the thing shipped."""
@@ -207,7 +242,7 @@ def main():
             nbytes = algorithmic_bytes(name, shape)
             ach = nbytes / (avg_ms * 1e-3) / 1e9
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                'frac': ach / HBM_PEAK_GBS, 'traffic': None, 'kernel': name, 'shape': list(shape),
+                                'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(name, shape), 'kernel': name, 'shape': list(shape),
                                 'avg_us': 1e3 * avg_ms, 'launches_per_step': n / args.steps,
                                 'algorithmic_bytes': nbytes}
             hot_ms = sum(v[0] for v in per.values()) / args.steps
