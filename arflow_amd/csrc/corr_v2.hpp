@@ -267,13 +267,17 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
     blk[m] = k;
     off[m] = piece_offset(k, lane, SR, SP / 4, ty0 - D, tx0 - D, H, W);
   }
-  auto issue = [&](int chunk) {
-    float* buf = lds + (chunk % NBUF) * BUF;
-    const float* g = srcb + (long)chunk * CC * cs;
+  // Channel chunks are independent in the backward (every output channel is its own sum), so when a level
+  // has few tiles the chunks are spread over gridDim.y workgroups: chunk k of this workgroup is channel
+  // chunk blockIdx.y + k * gridDim.y.  gout is then re-read per workgroup (from L2; small at such levels).
+  const int nsplit = gridDim.y, split = blockIdx.y;
+  auto issue = [&](int k) {
+    float* buf = lds + (k % NBUF) * BUF;
+    const float* g = srcb + (long)(split + k * nsplit) * CC * cs;
 #pragma unroll
     for (int m = 0; m < NK; ++m) dma16(off[m] >= 0 ? g + off[m] : g_zero16, buf + blk[m] * 256);
   };
-  const int nchunk = C / CC;
+  const int nchunk = (C / CC - split + nsplit - 1) / nsplit;  // chunks handled by this workgroup
 #pragma unroll
   for (int pre = 0; pre < NBUF - 1; ++pre)
     if (pre < nchunk) issue(pre);
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
       const float4 p2 = *reinterpret_cast<const float4*>(part + ((2 * CC + c) * 64 + l) * PX);
       const int oyy = ty0 + oy, oxx = tx0 + 4 * oxg;
       if (oyy < H && oxx < W)
-        *reinterpret_cast<float4*>(dstb + (long)(ch * CC + c) * cs + (long)oyy * W + oxx) =
+        *reinterpret_cast<float4*>(dstb + (long)((split + ch * nsplit) * CC + c) * cs + (long)oyy * W + oxx) =
             make_float4((p0.x + p1.x + p2.x) * inv_c, (p0.y + p1.y + p2.y) * inv_c, (p0.z + p1.z + p2.z) * inv_c,
                         (p0.w + p1.w + p2.w) * inv_c);
     }
@@ -386,7 +390,9 @@ inline int launch_bwd(const float* gout, const float* fout, float slope, const f
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B * nmodes;
-  dim3 grid(grid_for_tiles(tiles));
+  int nsplit = 1;  // spread channel chunks over workgroups until ~1024 are in flight
+  while (nsplit * 2 <= C / CC && tiles * nsplit * 2 <= 1024) nsplit *= 2;
+  dim3 grid(grid_for_tiles(tiles), nsplit);
   if (tiles >= 768)
     hipLaunchKernelGGL(bwd_kernel<2>, grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
                        gx1 ? 0 : 1, nmodes);

@@ -97,33 +97,46 @@ class CorrelationFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, max_displacement, negative_slope=1.0):
         _need_gpu(x1, x2)
-        x1, x2 = x1.contiguous(), x2.contiguous()
         if x1.shape != x2.shape or x1.dim() != 4:
             raise ValueError('correlation expects two [B,C,H,W] tensors of equal shape')
         B, C, H, W = x1.shape
         d = int(max_displacement)
         slope = float(negative_slope)
-        out = torch.empty(B, (2 * d + 1) ** 2, H, W, device=x1.device, dtype=torch.float32)
+        # The fast kernels need 16-byte aligned rows (W % 4 == 0).  Coarse pyramid levels such as 6x10 or
+        # 8x14 are not: zero-pad the width (identical results on the real columns -- the volume's own
+        # padding is zero as well), run the aligned kernel, crop.  The C ABI itself accepts any W.
+        wp = (-W) % 4 if (d == 4 and C % 4 == 0) else 0
+        if wp:
+            x1 = torch.nn.functional.pad(x1, (0, wp))
+            x2 = torch.nn.functional.pad(x2, (0, wp))
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        Wk = W + wp
+        out = torch.empty(B, (2 * d + 1) ** 2, H, Wk, device=x1.device, dtype=torch.float32)
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, W, d, slope, _stream(), key=(B, C, H, W, d))
+            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, Wk, d, slope, _stream(), key=(B, C, H, Wk, d))
         if slope != 1.0:
             ctx.save_for_backward(x1, x2, out)  # the sign of the output selects the LeakyReLU derivative
         else:
             ctx.save_for_backward(x1, x2)
-        ctx.d, ctx.slope = d, slope
-        return out
+        ctx.d, ctx.slope, ctx.w, ctx.wp = d, slope, W, wp
+        return out[..., :W].contiguous() if wp else out
 
     @staticmethod
     def backward(ctx, gout):
         x1, x2 = ctx.saved_tensors[:2]
         fout = ctx.saved_tensors[2] if ctx.slope != 1.0 else None
-        B, C, H, W = x1.shape
+        B, C, H, Wk = x1.shape
+        if ctx.wp:
+            gout = torch.nn.functional.pad(gout, (0, ctx.wp))
         gout = gout.contiguous()
         g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_bwd', _p(gout), _p(fout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, W, ctx.d, ctx.slope,
-                  _stream(), key=(B, C, H, W, ctx.d, fout is not None))
+            _call('arflow_corr_bwd', _p(gout), _p(fout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, Wk, ctx.d, ctx.slope,
+                  _stream(), key=(B, C, H, Wk, ctx.d, fout is not None))
+        if ctx.wp:
+            g1 = None if g1 is None else g1[..., :ctx.w].contiguous()
+            g2 = None if g2 is None else g2[..., :ctx.w].contiguous()
         return g1, g2, None, None
 
 

@@ -2,6 +2,7 @@
 of scope, SURVEY section 2 #14)."""
 from .flow_loss import unFlowLoss
 from .fullres_loss import FullResLoss
+from .mv_loss import MvLoss
 from .uflow_loss import UFlowLoss
 
 
@@ -12,4 +13,6 @@ def get_loss(cfg):
         return FullResLoss(cfg)
     if cfg.type == 'uflow':
         return UFlowLoss(cfg)
+    if cfg.type == 'mv':  # build-defined 3-frame objective; not a reference type
+        return MvLoss(cfg)
     raise NotImplementedError(cfg.type)

@@ -23,6 +23,11 @@ WORKLOADS = {
         dict(type='unflow', w_l1=0.15, w_ssim=0.85, w_ternary=0.0, warp_pad='border', alpha=10, occ_from_back=True,
              with_bk=True, w_smooth=75.0, w_scales=[1.0, 1.0, 1.0, 1.0, 1.0, 0.0],
              w_sm_scales=[1.0, 0.0, 0.0, 0.0, 0.0, 0.0])),
+    # BASELINE config 5: 3-frame PWCLite (forward_3_frames) + the build-defined multi-view objective
+    'pwclite3+mv_loss': (
+        dict(type='pwclite', upsample=True, n_frames=3, reduce_dense=True),
+        dict(type='mv', w_l1=0.15, w_ssim=0.85, alpha=10, w_smooth=75.0, w_scales=[1.0, 1.0, 1.0, 1.0, 0.0],
+             w_sm_scales=[1.0, 0.0, 0.0, 0.0, 0.0])),
     # BASELINE config 4: configs/chairs_uflow.json (model type 'uflow' = PWCFlow)
     'pwcflow+uflow_loss': (
         dict(type='uflow', feature_norm=True, level_dropout=0.1),
@@ -66,8 +71,11 @@ class TrainStep:
         if self.channels_last:
             img_pair = img_pair.contiguous(memory_format=torch.channels_last)
         res = self.model(img_pair, with_bk=True)
-        flows = [torch.cat([fw, bw], 1) for fw, bw in zip(res['flows_fw'], res['flows_bw'])]
-        out = self.loss(flows, img_pair)
+        if self.loss_cfg.type == 'mv':
+            out = self.loss(res['flows_fw'], res['flows_bw'], img_pair)
+        else:
+            flows = [torch.cat([fw, bw], 1) for fw, bw in zip(res['flows_fw'], res['flows_bw'])]
+            out = self.loss(flows, img_pair)
         self.reducer.zero_grad()
         out[0].backward()
         self.reducer.finish()

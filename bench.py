@@ -123,11 +123,12 @@ def cpu_baseline(workload, height, width, budget_s=25.0):
     model = get_model(AttrDict(mcfg))
     model.init_weights()
     model.train()
-    loss_cls = {'uflow': OL.UFlowLoss, 'unflow': OL.unFlowLoss, 'fullres': OL.FullResLoss}[lcfg['type']]
+    loss_cls = {'uflow': OL.UFlowLoss, 'unflow': OL.unFlowLoss, 'fullres': OL.FullResLoss, 'mv': OL.MvLoss}[lcfg['type']]
     loss = loss_cls(AttrDict(lcfg))
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     B = 1
-    x = synthetic_pairs(B, height, width, device='cpu')
+    frames = mcfg.get('n_frames', 2)
+    x = synthetic_pairs(B, height, width, frames=frames, device='cpu')
     # the GPU box gives one GPU a 16-core CPU share: more torch threads than that only oversubscribe
     cores = max(1, min(16, os.cpu_count() or 1))
     torch.set_num_threads(cores)
@@ -137,8 +138,11 @@ def cpu_baseline(workload, height, width, budget_s=25.0):
         for it in range(4):
             t0 = time.time()
             res = model(x, with_bk=True)
-            flows = [torch.cat([a, b], 1) for a, b in zip(res['flows_fw'], res['flows_bw'])]
-            out = loss(flows, x)
+            if lcfg['type'] == 'mv':
+                out = loss(res['flows_fw'], res['flows_bw'], x)
+            else:
+                flows = [torch.cat([a, b], 1) for a, b in zip(res['flows_fw'], res['flows_bw'])]
+                out = loss(flows, x)
             opt.zero_grad()
             out[0].backward()
             opt.step()
@@ -195,7 +199,7 @@ def main():
         torch.backends.cudnn.benchmark = True
     step = TrainStep(args.workload, device, seed=1234, channels_last=args.channels_last)
     torch.manual_seed(1000 + rank)  # level-dropout draws differ per rank, like independent workers
-    img = synthetic_pairs(args.batch, H, W, device=device, seed=100 + rank)
+    img = synthetic_pairs(args.batch, H, W, frames=step.model_cfg.get('n_frames', 2), device=device, seed=100 + rank)
 
     def sync():
         if use_dist:

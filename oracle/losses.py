@@ -184,3 +184,44 @@ class FullResLoss(nn.Module):
             im_s = F.interpolate(im_a, (h, w), mode='bilinear', align_corners=cfg.align_corners)
             loss_smooth = loss_smooth + self.loss_smooth(f_ab2, im_s.detach())
         return loss_warp + cfg.w_smooth * loss_smooth, loss_warp, loss_smooth, output[0].abs().mean()
+
+
+class MvLoss(nn.Module):
+    """CPU restatement of arflow_amd/losses/mv_loss.py -- the build-defined multi-view objective of
+    SURVEY App. B-10, composed of oracle functions only (flow_warp border, border_mask, L1 + SSIM,
+    smooth_grad_1st)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+    def forward(self, flows_12, flows_10, target):
+        cfg = self.cfg
+        im0, im1, im2 = target[:, 0:3], target[:, 3:6], target[:, 6:9]
+        warp_loss, smooth_loss = 0., 0.
+        s = 1.
+        for i, (f12, f10) in enumerate(zip(flows_12, flows_10)):
+            if cfg.w_scales[i] == 0:
+                continue
+            _, _, h, w = f12.shape
+            if i == 0:
+                s = min(h, w)
+            i1 = F.interpolate(im1, (h, w), mode='area')
+            l_warp, l_smooth = 0., 0.
+            for flow, im_k in ((f10, im0), (f12, im2)):
+                ik = F.interpolate(im_k, (h, w), mode='area')
+                rec = ops.flow_warp(ik, flow, pad='border')
+                m = ops.border_mask(flow)
+                photo = 0.
+                if cfg.w_l1 > 0:
+                    photo = photo + (cfg.w_l1 * (i1 - rec).abs() * m).mean()
+                if cfg.w_ssim > 0:
+                    photo = photo + (cfg.w_ssim * ops.ssim(rec * m, i1 * m)).mean()
+                l_warp = l_warp + photo / (m.mean() + 1e-6)
+                if cfg.w_sm_scales[i] != 0:
+                    l_smooth = l_smooth + ops.smooth_grad_1st(flow / s, i1, cfg.alpha)
+            warp_loss = warp_loss + cfg.w_scales[i] * l_warp / 2.
+            smooth_loss = smooth_loss + cfg.w_sm_scales[i] * l_smooth / 2.
+        smooth_loss = cfg.w_smooth * smooth_loss
+        mean_flow = (flows_12[0].abs().mean() + flows_10[0].abs().mean()) / 2.
+        return warp_loss + smooth_loss, warp_loss, smooth_loss, mean_flow

@@ -350,3 +350,32 @@ def test_determinism_of_atomic_free_kernels(AF):
         outs.append((y.detach().clone(),) + tuple(t.clone() for t in torch.autograd.grad(y, [x1, x2], go)))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_mv_loss_vs_oracle():
+    """BASELINE config 5 wiring (build-defined): product MvLoss on the HIP kernels vs the
+    same composition of oracle functions, values and gradients w.r.t. every flow level."""
+    from arflow_amd.config import AttrDict
+    from arflow_amd.losses import MvLoss
+    from oracle import losses as OL
+    from oracle.fixture_common import synth_pair
+    gen = torch.Generator().manual_seed(31)
+    img6, _ = synth_pair(2, 64, 96, gen)
+    img = torch.cat([img6, synth_pair(2, 64, 96, gen)[0][:, :3]], 1)
+    sizes = [(64, 96), (32, 48), (16, 24), (8, 12)]
+    f12 = [1.5 * torch.randn(2, 2, h, w, generator=gen) for h, w in sizes]
+    f10 = [1.5 * torch.randn(2, 2, h, w, generator=gen) for h, w in sizes]
+    cfg = AttrDict(w_l1=0.15, w_ssim=0.85, alpha=10, w_smooth=75.0, w_scales=[1.0, 1.0, 0.5, 1.0],
+                   w_sm_scales=[1.0, 0.5, 0.0, 0.0])
+    a12 = [f.clone().requires_grad_(True) for f in f12]
+    a10 = [f.clone().requires_grad_(True) for f in f10]
+    ref = OL.MvLoss(cfg)(a12, a10, img)
+    rg = torch.autograd.grad(ref[0], a12 + a10)
+    c12 = [cu(f).requires_grad_(True) for f in f12]
+    c10 = [cu(f).requires_grad_(True) for f in f10]
+    got = MvLoss(cfg)(c12, c10, cu(img))
+    for k in range(4):
+        assert_close(got[k], ref[k], 1e-6, 1e-4, 'mv loss term %d' % k)
+    gg = torch.autograd.grad(got[0], c12 + c10)
+    for a, b in zip(gg, rg):
+        assert_close(a, b, 2e-7 + 2e-4 * float(b.abs().max()), 2e-3, 'mv dflow')
