@@ -74,7 +74,8 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
                                     const TapPlan& p, bool inside, int C, int ss, int os, int Ws, int ax0, int by0,
                                     int bh, int l0, int l1, int l2, int l3) {
   constexpr int WP = 4 * WQ;
-  for (int c0 = 0; c0 < C; c0 += CCH) {
+  // channels are independent: at small levels they are spread over gridDim.y workgroups per tile
+  for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
     // stage CCH channels of the window: bh rows x WQ aligned float4 each
     const int per = bh * WQ;
 #pragma unroll
@@ -185,12 +186,13 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
   }
   if (!inside) return;
   if (empty) {
-    for (int c = 0; c < C; ++c) op[(long)c * os] = 0.f;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) op[(long)c * os] = 0.f;
     return;
   }
   // fallback: direct gathers, U channels per round (all 4*U loads in flight together)
   constexpr int U = 4;
-  for (int c0 = 0; c0 < C; c0 += U) {
+  static_assert(U == CCH, "channel split assumes U == CCH");
+  for (int c0 = blockIdx.y * U; c0 < C; c0 += gridDim.y * U) {
     float a[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -262,7 +264,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
                                     int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
                                     float& gix, float& giy) {
   constexpr int WP = 4 * WQ;
-  for (int c0 = 0; c0 < C; c0 += CCH) {
+  for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
     const int per = bh * WQ;
     float g[CCH];
 #pragma unroll
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
       flow_grad::run<18>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa, cya * 72 + cxb,
                          cyb * 72 + cxa, cyb * 72 + cxb, gix, giy);
   } else if (inside && !empty) {
-    for (int c = 0; c < C; ++c) {  // direct gathers (window too large or unaligned rows)
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {  // direct gathers (window too large or unaligned rows)
       const float g = gop[(long)c * os];
       const float* s = sp + (long)c * ss;
       float a0 = s[p.o[0]], a1 = s[p.o[1]], a2 = s[p.o[2]], a3 = s[p.o[3]];
@@ -343,8 +345,13 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
   }
   if (inside) {
     float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
-    gf[0] = gix * t.dx;
-    gf[os] = giy * t.dy;
+    if (gridDim.y == 1) {
+      gf[0] = gix * t.dx;
+      gf[os] = giy * t.dy;
+    } else {  // channel-split launch: partial sums meet in the pre-zeroed gflow
+      atomicAdd(gf, gix * t.dx);
+      atomicAdd(gf + os, giy * t.dy);
+    }
   }
 }
 
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
 
   if (!priv) {
     if (inside)
-      for (int c = 0; c < C; ++c) {
+      for (int c = blockIdx.y; c < C; c += gridDim.y) {
         const float g = gop[c * os];
         float* d = gp + c * ss + o00;
         if (ok[0]) atomicAdd(d, g * wgt[0]);
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
   __syncthreads();
   // 4. per channel chunk: stage gout, gather per non-empty cell, one global atomic per cell and channel
   int buf = 0;
-  for (int c0 = 0; c0 < C; c0 += CCH, buf ^= 1) {
+  for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH, buf ^= 1) {
 #pragma unroll
     for (int c = 0; c < CCH; ++c) gt[buf][c][threadIdx.x] = (c0 + c < C && inside) ? gop[(c0 + c) * os] : 0.f;
     __syncthreads();
@@ -505,46 +512,114 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
 }
 }  // namespace lds_scatter
 
-// forward splat of the 4 bilinear weights of every pixel's target position
-__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ flow, float* __restrict__ out,
-                                                    int H, int W, long fbs, int variant) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y, b = blockIdx.z;
-  if (x >= W) return;
-  const float* fb = flow + (long)b * fbs + (long)y * W + x;
-  const bool abs_in = (variant & ARFLOW_COORDS_ABS) != 0;
-  const float cx = abs_in ? fb[0] : (float)x + fb[0], cy = abs_in ? fb[(long)H * W] : (float)y + fb[(long)H * W];
+// Forward splat of the 4 bilinear weights of every pixel's target position (compute_range_map /
+// get_corresponding_map).  One workgroup = an 8 x 32 tile of source pixels; their targets fall into a
+// small window that is accumulated in LDS with INTEGER atomics on 2^-22 fixed-point weights
+// (ds_add_u32 is ~25x faster than ds_add_f32 on gfx950, and integer sums do not depend on the order),
+// then every touched cell is flushed with one global float atomic.  The direct form -- four global
+// atomics per pixel, with same-address collisions inside a wave wherever the flow compresses -- took
+// 128 us for 8 x 384 x 640.  Weight quantisation error <= 1.2e-7 per tap.  Windows larger than
+// 128 x 64 fall back to direct atomics.
+struct SplatTaps {
+  int xi[4], yi[4];
+  float w[4];
+  bool ok[4];
+};
+__device__ __forceinline__ SplatTaps splat_taps(float cx, float cy, int H, int W, int variant) {
+  SplatTaps t;
   const float fx = floorf(cx), fy = floorf(cy);
-  float* ob = out + (long)b * H * W;
   if ((variant & 1) == 0) {
-    // compute_range_map: weights from the fractional offset, out-of-image taps dropped
     const float ox = cx - fx, oy = cy - fy;
 #pragma unroll
-    for (int di = 0; di < 2; ++di)
-#pragma unroll
-      for (int dj = 0; dj < 2; ++dj) {
-        const float yi = fy + di, xj = fx + dj;
-        if (yi >= 0.f && yi < (float)H && xj >= 0.f && xj < (float)W) {
-          const float w = (di ? oy : 1.f - oy) * (dj ? ox : 1.f - ox);
-          atomicAdd(ob + (long)(int)yi * W + (int)xj, w);
-        }
-      }
+    for (int k = 0; k < 4; ++k) {
+      const int di = k >> 1, dj = k & 1;
+      const float yi = fy + di, xj = fx + dj;
+      t.ok[k] = yi >= 0.f && yi < (float)H && xj >= 0.f && xj < (float)W;
+      t.w[k] = (di ? oy : 1.f - oy) * (dj ? ox : 1.f - ox);
+      t.yi[k] = t.ok[k] ? (int)yi : 0;
+      t.xi[k] = t.ok[k] ? (int)xj : 0;
+    }
   } else {
-    // get_corresponding_map: indices clamped into the image, weight (1-|x-xi|)(1-|y-yi|) with the
-    // CLAMPED corner, zero when the un-clamped corner was outside
     const float xw = (float)(W - 1), yh = (float)(H - 1);
 #pragma unroll
-    for (int di = 0; di < 2; ++di)
-#pragma unroll
-      for (int dj = 0; dj < 2; ++dj) {
-        const float yr = fy + di, xr = fx + dj;
-        const float yc = fminf(fmaxf(yr, 0.f), yh), xc = fminf(fmaxf(xr, 0.f), xw);
-        if (yc == yr && xc == xr) {
-          const float w = (1.f - fabsf(cx - xc)) * (1.f - fabsf(cy - yc));
-          atomicAdd(ob + (long)(int)yc * W + (int)xc, w);
-        }
-      }
+    for (int k = 0; k < 4; ++k) {
+      const int di = k >> 1, dj = k & 1;
+      const float yr = fy + di, xr = fx + dj;
+      const float yc = fminf(fmaxf(yr, 0.f), yh), xc = fminf(fmaxf(xr, 0.f), xw);
+      t.ok[k] = yc == yr && xc == xr;
+      t.w[k] = (1.f - fabsf(cx - xc)) * (1.f - fabsf(cy - yc));
+      t.yi[k] = t.ok[k] ? (int)yc : 0;
+      t.xi[k] = t.ok[k] ? (int)xc : 0;
+    }
   }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ flow, float* __restrict__ out,
+                                                    int nimg, int H, int W, long fbs, int variant) {
+  constexpr int WMAX = 128, HMAX = 64;
+  constexpr float FIX = 4194304.f;  // 2^22
+  __shared__ unsigned cellv[WMAX * HMAX];
+  __shared__ int red[4][4];
+  __shared__ int box[4];
+  int btx, bty, b;
+  if (!af_tile_of_block((W + 31) / 32, (H + 7) / 8, nimg, btx, bty, b)) return;
+  const int x = btx * 32 + (int)(threadIdx.x & 31), y = bty * 8 + (int)(threadIdx.x >> 5);
+  const bool inside = x < W && y < H;
+  SplatTaps t;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t.ok[k] = false, t.xi[k] = t.yi[k] = 0, t.w[k] = 0.f;
+  if (inside) {
+    const float* fb = flow + (long)b * fbs + (long)y * W + x;
+    const bool abs_in = (variant & ARFLOW_COORDS_ABS) != 0;
+    const float cx = abs_in ? fb[0] : (float)x + fb[0], cy = abs_in ? fb[(long)H * W] : (float)y + fb[(long)H * W];
+    t = splat_taps(cx, cy, H, W, variant);
+  }
+  // bounding box of the valid targets
+  int lo_x = 0x7fffffff, lo_y = 0x7fffffff, hi_x = -0x7fffffff, hi_y = -0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.ok[k]) {
+      lo_x = min(lo_x, t.xi[k]), hi_x = max(hi_x, t.xi[k]);
+      lo_y = min(lo_y, t.yi[k]), hi_y = max(hi_y, t.yi[k]);
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_x = min(lo_x, __shfl_xor(lo_x, off, 64));
+    lo_y = min(lo_y, __shfl_xor(lo_y, off, 64));
+    hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
+    hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[0][wave] = lo_x, red[1][wave] = lo_y, red[2][wave] = hi_x, red[3][wave] = hi_y;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = red[0][0], bb = red[1][0], c = red[2][0], d = red[3][0];
+    for (int w = 1; w < 4; ++w) a = min(a, red[0][w]), bb = min(bb, red[1][w]), c = max(c, red[2][w]), d = max(d, red[3][w]);
+    box[0] = a, box[1] = bb, box[2] = c, box[3] = d;
+  }
+  __syncthreads();
+  const int bx0 = box[0], by0 = box[1], bw = box[2] - bx0 + 1, bh = box[3] - by0 + 1;
+  if (box[2] < bx0) return;  // nothing lands inside the image
+  float* ob = out + (long)b * H * W;
+  if (bw > WMAX || bh > HMAX) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (t.ok[k]) atomicAdd(ob + (long)t.yi[k] * W + t.xi[k], t.w[k]);
+    return;
+  }
+  const int wp = (bw + 31) & ~31;
+  for (int i = threadIdx.x; i < bh * wp; i += 256) cellv[i] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (t.ok[k]) atomicAdd(&cellv[(t.yi[k] - by0) * wp + (t.xi[k] - bx0)], (unsigned)__float2int_rn(t.w[k] * FIX));
+  __syncthreads();
+  for (int r = wave; r < bh; r += 4)
+    for (int c = lane; c < bw; c += 64) {
+      const unsigned v = cellv[r * wp + c];
+      if (v) atomicAdd(ob + (long)(by0 + r) * W + bx0 + c, (float)v * (1.f / FIX));
+    }
 }
 
 __global__ __launch_bounds__(256) void coord_mask_kernel(const float* __restrict__ flow,
@@ -593,6 +668,13 @@ __global__ __launch_bounds__(256) void occ_bidir_kernel(const float* __restrict_
 }
 
 inline dim3 pixel_grid(int B, int H, int W, int bx) { return dim3(af_cdiv(W, bx), H, B); }
+// Few tiles (coarse pyramid levels): spread the 4-channel chunks of a tile over up to C/4 workgroups until
+// ~2048 workgroups are in flight, instead of one workgroup walking all channels serially.
+inline unsigned channel_split(long tiles, int C) {
+  unsigned n = 1;
+  while ((long)n * 2 <= C / 4 && tiles * n * 2 <= 2048) n *= 2;
+  return n;
+}
 inline int pick_bx(int W) { return W >= 192 ? 256 : (W >= 96 ? 128 : 64); }
 
 }  // namespace
@@ -609,8 +691,9 @@ extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, 
   AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
   AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
   const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
-  hipLaunchKernelGGL(warp_fwd_kernel, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, (hipStream_t)stream, src, flow,
-                     out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  hipLaunchKernelGGL(warp_fwd_kernel, dim3(af_grid_for_tiles(tiles), channel_split(tiles, C)), dim3(256), 0,
+                     (hipStream_t)stream, src, flow, out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode,
+                     align_corners, norm_mode);
   return af_launch_status();
 }
 
@@ -632,12 +715,18 @@ extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float*
     if (e != hipSuccess) return af_hip_status(e);
   }
   const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  const unsigned nsplit = channel_split(tiles, C);
   if (gsrc)
-    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, gout, flow,
-                       gsrc, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
-  if (gflow)
-    hipLaunchKernelGGL(warp_bwd_flow_kernel, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, gout, src, flow, gflow, B,
-                       C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
+                       flow, gsrc, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  if (gflow) {
+    if (nsplit > 1) {
+      hipError_t e = hipMemsetAsync(gflow, 0, sizeof(float) * (size_t)B * 2 * H * W, st);
+      if (e != hipSuccess) return af_hip_status(e);
+    }
+    hipLaunchKernelGGL(warp_bwd_flow_kernel, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
+                       gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  }
   return af_launch_status();
 }
 
@@ -651,8 +740,8 @@ extern "C" int arflow_splat_map(const float* flow, float* out, int B, int H, int
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * H * W, st);
   if (e != hipSuccess) return af_hip_status(e);
-  const int bx = pick_bx(W);
-  hipLaunchKernelGGL(splat_kernel, pixel_grid(B, H, W, bx), dim3(bx), 0, st, flow, out, H, W, flow_bstride,
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  hipLaunchKernelGGL(splat_kernel, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, flow, out, B, H, W, flow_bstride,
                      variant);
   return af_launch_status();
 }

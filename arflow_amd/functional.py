@@ -148,8 +148,11 @@ def correlation(x1, x2, max_displacement=4, negative_slope=1.0):
 
 # ------------------------------------------------------------------------------------------------
 class WarpFunction(torch.autograd.Function):
+    """out = bilinear(src, grid + flow); with ``want_valid`` also the in-image mask of the sampling
+    positions (mask_invalid(flow_to_warp(flow)), utils/uflow_utils.py:35-50) from the same launch."""
+
     @staticmethod
-    def forward(ctx, src, flow, pad, align_corners, norm):
+    def forward(ctx, src, flow, pad, align_corners, norm, want_valid=False):
         _need_gpu(src, flow)
         src = src.contiguous()
         flow, fbs = _flow_view(flow)
@@ -158,15 +161,19 @@ class WarpFunction(torch.autograd.Function):
         if flow.shape[0] != B:
             raise ValueError('batch mismatch between source and flow')
         out = torch.empty(B, C, H, W, device=src.device, dtype=torch.float32)
+        valid = torch.empty(B, 1, H, W, device=src.device, dtype=torch.float32) if want_valid else None
         with torch.cuda.device_of(src):
-            _call('arflow_warp_fwd', _p(src), _p(flow), _p(out), None, B, C, Hs, Ws, H, W, fbs, pad,
+            _call('arflow_warp_fwd', _p(src), _p(flow), _p(out), _p(valid), B, C, Hs, Ws, H, W, fbs, pad,
                   int(bool(align_corners)), norm, _stream(), key=(B, C, H, W))
         ctx.save_for_backward(src, flow)
         ctx.cfg = (pad, int(bool(align_corners)), norm, fbs)
+        if want_valid:
+            ctx.mark_non_differentiable(valid)
+            return out, valid
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *unused):
         src, flow = ctx.saved_tensors
         pad, ac, norm, fbs = ctx.cfg
         B, C, Hs, Ws = src.shape
@@ -177,11 +184,16 @@ class WarpFunction(torch.autograd.Function):
         with torch.cuda.device_of(src):
             _call('arflow_warp_bwd', _p(gout), _p(src), _p(flow), _p(gsrc), _p(gflow), B, C, Hs, Ws, H, W, fbs,
                   pad, ac, norm, _stream(), key=(B, C, H, W, gsrc is not None))
-        return gsrc, gflow, None, None, None
+        return gsrc, gflow, None, None, None, None
 
 
 def warp(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW):
     return WarpFunction.apply(src, flow, PAD[pad], align_corners, norm)
+
+
+def warp_with_valid(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW):
+    """(warped, valid mask) in one launch."""
+    return WarpFunction.apply(src, flow, PAD[pad], align_corners, norm, True)
 
 
 def _flow_map(name, flow, *extra):

@@ -21,8 +21,7 @@ class UFlowLoss(nn.Module):
     def _direction(self, im_a, im_b, flow_ab0, flow_ba2, flow_ab2):
         cfg = self.cfg
         # im_a ~ warp(im_b, flow_ab0); only d/d flow is needed (source detached, uflow_loss.py:31,34)
-        recons = AF.warp(im_b.detach(), flow_ab0, pad='zeros', align_corners=True, norm=AF.NORM_UFLOW)
-        valid = AF.coord_mask(flow_ab0, 0)
+        recons, valid = AF.warp_with_valid(im_b.detach(), flow_ab0, pad='zeros', align_corners=True, norm=AF.NORM_UFLOW)
         occ_small = AF.splat_map(flow_ba2, 0)
         mask = AF.up4_clamp_mul(occ_small, valid)
         l_census = cfg.w_census * census_loss(im_a, recons, mask)

@@ -23,6 +23,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def _use_shipped_miopen_db():
+    """Point MIOpen at the tuning records shipped in arflow_amd/miopen_db (found on an MI355X with
+    `--miopen-find`).  The convolutions of the host model are MIOpen's (outside the hot
+    path); without the records MIOpen's immediate mode falls back to its heuristic solver choice, which is
+    ~5 % slower on this network.  The records are copied to a private per-rank directory because MIOpen
+    opens its user database read-write.  Set ARFLOW_MIOPEN_DB=off to skip."""
+    if os.environ.get('ARFLOW_MIOPEN_DB', 'on') == 'off' or 'MIOPEN_USER_DB_PATH' in os.environ:
+        return
+    import shutil
+    import tempfile
+    src = os.path.join(ROOT, 'arflow_amd', 'miopen_db')
+    if not os.path.isdir(src):
+        return
+    dst = os.path.join(tempfile.gettempdir(), 'arflow_miopen_db_%d_r%s' % (os.getuid(), os.environ.get('LOCAL_RANK', '0')))
+    try:
+        os.makedirs(dst, exist_ok=True)
+        for f in os.listdir(src):
+            if f.endswith('.txt'):
+                shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+        os.environ['MIOPEN_USER_DB_PATH'] = dst
+    except OSError:
+        pass
+
+
+_use_shipped_miopen_db()
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -168,7 +196,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations for MIOpen')
-    ap.add_argument('--miopen-benchmark', action='store_true', help='experiment: exhaustive MIOpen find')
+    ap.add_argument('--miopen-find', '--miopen-benchmark', dest='miopen_benchmark', action='store_true',
+                    help='let MIOpen time every solver per convolution (slow the first time; results go to MIOPEN_USER_DB_PATH)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
