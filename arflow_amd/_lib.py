@@ -18,8 +18,9 @@ c_f = ctypes.c_float
 # name -> argtypes, exactly the prototypes of include/arflow_hip.h
 PROTOTYPES = {
     'arflow_abi_version': [],
-    'arflow_corr_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
-    'arflow_corr_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'arflow_corr_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'arflow_corr_sign_planes': [c_i, c_i, c_i],
+    'arflow_corr_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_warp_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_warp_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_splat_map': [c_fp, c_fp, c_i, c_i, c_i, c_l, c_i, c_fp],
@@ -35,7 +36,7 @@ PROTOTYPES = {
     'arflow_up4_clamp_mul': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

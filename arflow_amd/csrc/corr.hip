@@ -347,8 +347,12 @@ int dispatch_bwd(const float* gout, const float* fout, float slope, const float*
 
 }  // namespace
 
-extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W,
-                               int max_disp, float negative_slope, arflow_stream_t stream) {
+extern "C" int arflow_corr_sign_planes(int C, int W, int max_disp) {
+  return corr_v2::eligible(C, W, max_disp) ? corr_v2::NW : 0;
+}
+
+extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C,
+                               int H, int W, int max_disp, float negative_slope, arflow_stream_t stream) {
   const float slope = negative_slope;
   AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
@@ -357,7 +361,8 @@ extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, int
   AF_REQUIRE(max_disp >= 1, ARFLOW_EPARAM);
   AF_REQUIRE(B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  if (corr_v2::eligible(C, W, max_disp)) return corr_v2::launch_fwd(x1, x2, out, B, C, H, W, slope, st);
+  if (corr_v2::eligible(C, W, max_disp)) return corr_v2::launch_fwd(x1, x2, out, sign_bits, B, C, H, W, slope, st);
+  AF_REQUIRE(sign_bits == nullptr, ARFLOW_EPARAM);  // only the fast path records signs
   switch (max_disp) {
     case 1: return dispatch_fwd<1>(x1, x2, out, B, C, H, W, slope, st);
     case 2: return dispatch_fwd<2>(x1, x2, out, B, C, H, W, slope, st);
@@ -373,21 +378,26 @@ extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, int
   }
 }
 
-extern "C" int arflow_corr_bwd(const float* gout, const float* out, const float* x1, const float* x2, float* gx1,
-                               float* gx2, int B, int C, int H, int W, int max_disp, float negative_slope,
-                               arflow_stream_t stream) {
+extern "C" int arflow_corr_bwd(const float* gout, const float* out, const unsigned* sign_bits, const float* x1,
+                               const float* x2, float* gx1, float* gx2, int B, int C, int H, int W, int max_disp,
+                               float negative_slope, arflow_stream_t stream) {
   AF_REQUIRE_PTR(gout);
   const float slope = negative_slope;
-  const float* fout = negative_slope != 1.0f ? out : nullptr;
-  if (negative_slope != 1.0f) AF_REQUIRE_PTR(out);
+  const bool act = negative_slope != 1.0f;
+  const bool fast = corr_v2::eligible(C, W, max_disp);
+  if (!(act && fast)) sign_bits = nullptr;  // the generic kernels read `out`
+  const float* fout = (act && !sign_bits) ? out : nullptr;
+  if (act && !sign_bits) {
+    AF_REQUIRE_PTR(out);
+    AF_REQUIRE(negative_slope >= 0.f, ARFLOW_EPARAM);  // out > 0 <=> pre-activation > 0 only then
+  }
   AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
   AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, ARFLOW_ESHAPE);
   AF_REQUIRE(max_disp >= 1, ARFLOW_EPARAM);
   AF_REQUIRE(2 * B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  if (corr_v2::eligible(C, W, max_disp))
-    return corr_v2::launch_bwd(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+  if (fast) return corr_v2::launch_bwd(gout, fout, sign_bits, slope, x1, x2, gx1, gx2, B, C, H, W, st);
   switch (max_disp) {
     case 1: return dispatch_bwd<1>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
     case 2: return dispatch_bwd<2>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);

@@ -67,17 +67,21 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// The empty asm pins each read as ONE ds_read_b128.  Left alone, hipcc re-splits the window into
-// ds_read2_b32 pairs (to feed v_pk_fma_f32 operands at odd offsets), which bank-conflict (32-bank
-// mode) and double the LDS instruction count: measured 57 % of LDS cycles lost in the backward kernel.
-__device__ __forceinline__ void load_window(const float* row, float (&w)[PX + 2 * D]) {
+// A 12-float window row is read as THREE ds_read_b128, issued together one step ahead of their use
+// (issue_window) and unpacked after the FMAs of the current step (land_window).  The empty asm in
+// land_window pins each read as ONE ds_read_b128: left alone, hipcc re-splits the window into
+// ds_read2_b32 pairs (to feed v_pk_fma_f32 operands at odd offsets), which bank-conflict (32-bank mode)
+// and double the LDS instruction count (measured 57 % of LDS cycles lost in the backward kernel).  The pin
+// sits at the point of USE, not at the load: pinned at the load, every read was followed by its own
+// s_waitcnt lgkmcnt(0) -- ten serialised LDS round trips per channel.
+__device__ __forceinline__ void issue_window(const float* row, f32x4 (&t)[3]) {
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * q);
-    asm volatile("" : "+v"(t));
-    w[4 * q] = t.x, w[4 * q + 1] = t.y, w[4 * q + 2] = t.z, w[4 * q + 3] = t.w;
-  }
+  for (int q = 0; q < 3; ++q) t[q] = *reinterpret_cast<const f32x4*>(row + 4 * q);
 }
+__device__ __forceinline__ void land_window(f32x4 (&t)[3]) {
+  asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]));
+}
+#define CORR_WIN(t, i) ((t)[(i) >> 2][(i) & 3])  // element i (compile-time) of a landed window
 __device__ __forceinline__ void load_vec4(const float* p, float (&v)[PX]) {
   f32x4 t = *reinterpret_cast<const f32x4*>(p);
   asm volatile("" : "+v"(t));
@@ -103,11 +107,11 @@ inline unsigned grid_for_tiles(int T) { return 8u * (unsigned)((T + 7) / 8); }
 // ------------------------------------------------------------------------------------------------
 template <int NBUF>
 __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                    float* __restrict__ out, int nimg, int C, int H, int W,
-                                                    float inv_c, float slope) {
+                                                    float* __restrict__ out, unsigned* __restrict__ sign_bits,
+                                                    int nimg, int C, int H, int W, float inv_c, float slope) {
   constexpr int BUF = SRC_FLOATS + X1_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + TH * SP];  // + pad: prefetch runs a channel ahead
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave id in an SGPR
   int xg, y;
   lane_xy(lane, xg, y);
   int btx, bty, b;
@@ -163,37 +167,35 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
     // software-pipelined over the 12 (channel, row-shift) steps: the window of the next step is
     // requested before the 108 FMAs of the current one so the LDS latency hides behind them.  The
     // prefetch past the last channel reads the next region of the LDS array (in bounds, unused).
-    float w[2][PX + 2 * D];
-    float a[PX], an[PX];
-    load_window(s2, w[0]);
+    f32x4 wc[3], wn[3];
+    float a[PX];
+    issue_window(s2, wc);
+    land_window(wc);
     load_vec4(s1, a);
 #pragma unroll 1
     for (int c = 0; c < CC; ++c) {
       const float* sc = s2 + c * SR * SP;
+      f32x4 ta;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        if (k < 2) {
-          load_window(sc + (k + 1) * SP, w[(k + 1) & 1]);
-        } else {
-          load_window(sc + SR * SP, w[(k + 1) & 1]);
-          load_vec4(s1 + (c + 1) * TH * SP, an);
-        }
+        issue_window(k < 2 ? sc + (k + 1) * SP : sc + SR * SP, wn);
+        if (k == 2) ta = *reinterpret_cast<const f32x4*>(s1 + (c + 1) * TH * SP);
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-          for (int p = 0; p < PX; ++p) acc[k][j][p] = fmaf(a[p], w[k & 1][j + p], acc[k][j][p]);
+          for (int p = 0; p < PX; ++p) acc[k][j][p] = fmaf(a[p], CORR_WIN(wc, j + p), acc[k][j][p]);
+        land_window(wn);
+        wc[0] = wn[0], wc[1] = wn[1], wc[2] = wn[2];
       }
-      // after 3 steps the "next" window sits in w[1]; it becomes w[0] of the next channel
-#pragma unroll
-      for (int q = 0; q < PX + 2 * D; ++q) w[0][q] = w[1][q];
-#pragma unroll
-      for (int p = 0; p < PX; ++p) a[p] = an[p];
+      asm volatile("" : "+v"(ta));
+      a[0] = ta.x, a[1] = ta.y, a[2] = ta.z, a[3] = ta.w;
     }
   }
 
   const int gy = ty0 + y, gx = tx0 + 4 * xg;
   if (gy >= H || gx >= W) return;
   float* ob = out + (((long)b * N * N + 3 * wave * N) * H + gy) * W + gx;
+  unsigned sg[PX] = {0u, 0u, 0u, 0u};  // bit k*9+j: this wave's channel (3*wave+k)*9+j is positive
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -202,18 +204,24 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
 #pragma unroll
       for (int p = 0; p < PX; ++p) {
         v[p] = acc[k][j][p] * inv_c;
+        sg[p] |= v[p] > 0.f ? 1u << (k * N + j) : 0u;
         v[p] = v[p] > 0.f ? v[p] : v[p] * slope;  // fused LeakyReLU (slope 1 = identity)
       }
       *reinterpret_cast<float4*>(ob + (k * N + j) * cs) = make_float4(v[0], v[1], v[2], v[3]);
     }
+  if (sign_bits)
+    *reinterpret_cast<uint4*>(sign_bits + (((long)b * NW + wave) * H + gy) * W + gx) = make_uint4(sg[0], sg[1], sg[2], sg[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
 // mode 0: gx1[c,p] = (1/C) sum_{i,j} g[i*9+j][p]        * x2[c][p+(i-4,j-4)]
 // mode 1: gx2[c,q] = (1/C) sum_{i,j} g[80-(i*9+j)][q+(i-4,j-4)] * x1[c][q+(i-4,j-4)]
-template <int NBUF>
+// ACT: how the fused LeakyReLU derivative is selected -- 0 none (slope 1), 1 sign of the forward output
+// `fout`, 2 the forward's compact sign words.
+template <int NBUF, int ACT>
 __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ gout, const float* __restrict__ fout,
-                                                    float slope, const float* __restrict__ x1,
+                                                    const unsigned* __restrict__ sign_bits, float slope,
+                                                    const float* __restrict__ x1,
                                                     const float* __restrict__ x2, float* __restrict__ gx1,
                                                     float* __restrict__ gx2, int B, int C, int H, int W,
                                                     float inv_c, int mode_base, int nmodes) {
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   constexpr int PART = NW * CC * 64 * PX;  // 3072 floats
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + PART];
   float* part = lds + NBUF * BUF;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave id in an SGPR
   int xg, y;
   lane_xy(lane, xg, y);
   // both gradients of a tile sit next to each other in the XCD's tile run (mode is the fastest index):
@@ -244,17 +252,23 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * cs;
   float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * cs;
   const float* gb = gout + (long)b * N * N * cs;
-  const float* fb = fout ? fout + (long)b * N * N * cs : nullptr;  // forward output: LeakyReLU derivative
+  const float* fb = ACT == 1 ? fout + (long)b * N * N * cs : nullptr;  // forward output: LeakyReLU derivative
   const int gy = ty0 + y, gx = tx0 + 4 * xg;
-  auto load4 = [&](long off) {  // 4 output gradients through the fused LeakyReLU
-    float4 t = *reinterpret_cast<const float4*>(gb + off);
-    if (fb) {
-      const float4 f = *reinterpret_cast<const float4*>(fb + off);
+  // Every load of the gradient phase is UNCONDITIONAL: a piece outside the image reads the 16 zero bytes
+  // of g_zero16 instead of being branched around.  With branches hipcc waits for each load before the
+  // next one is issued (s_waitcnt vmcnt(0) per displacement: 27+ serialised round trips per workgroup,
+  // two thirds of the kernel's wave-time measured); without them a whole row shift is in flight at once.
+  auto load4 = [&](bool ok, long off) {  // 4 output gradients through the fused LeakyReLU
+    float4 t = *reinterpret_cast<const float4*>(ok ? gb + off : g_zero16);
+    if (ACT == 1) {
+      const float4 f = *reinterpret_cast<const float4*>(ok ? fb + off : g_zero16);
       t.x = f.x > 0.f ? t.x : t.x * slope, t.y = f.y > 0.f ? t.y : t.y * slope;
       t.z = f.z > 0.f ? t.z : t.z * slope, t.w = f.w > 0.f ? t.w : t.w * slope;
     }
     return t;
   };
+  // compact alternative to `fout`: the forward's sign words (plane w holds the 27 channels of wave w)
+  const unsigned* sb = ACT == 2 ? sign_bits + (long)b * NW * cs : nullptr;
 
   // 10 DMA instructions per chunk over 3 waves: every wave issues 4 (the surplus two re-send piece 9,
   // identical bytes to the same LDS block) so that the per-wave count is a compile-time constant
@@ -282,39 +296,79 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   for (int pre = 0; pre < NBUF - 1; ++pre)
     if (pre < nchunk) issue(pre);
 
-  // the 27 x 4 output gradients this lane combines, read once
+  // the 27 x 4 output gradients this lane combines, read once.  The two modes are separate straight-line
+  // regions under ONE workgroup-uniform branch, so that the loads of a row shift are scheduled together.
   float g[3][N][PX];
+  const unsigned* zu = reinterpret_cast<const unsigned*>(g_zero16);
+  if (mode == 0) {
+    const bool ok = gy < H && gx < W;
+    unsigned pk[PX] = {0u, 0u, 0u, 0u};  // ACT == 2: plane-`wave` sign words of the lane's own 4 pixels
+    if (ACT == 2) {
+      const uint4 t = *reinterpret_cast<const uint4*>(ok ? sb + (long)wave * cs + (long)gy * W + gx : zu);
+      pk[0] = t.x, pk[1] = t.y, pk[2] = t.z, pk[3] = t.w;
+    }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = 3 * wave + k;
+    for (int k = 0; k < 3; ++k) {
+      const int i = 3 * wave + k;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      if (mode == 0) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy < H && gx < W) t = load4((i * N + j) * cs + (long)gy * W + gx);
+      for (int j = 0; j < N; ++j) {
+        const float4 t = load4(ok, (i * N + j) * cs + (long)gy * W + gx);
         g[k][j][0] = t.x, g[k][j][1] = t.y, g[k][j][2] = t.z, g[k][j][3] = t.w;
-      } else {
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+          if (ACT == 2 && !((pk[p] >> (k * N + j)) & 1u)) g[k][j][p] *= slope;
+        if (ACT == 1 && j % 3 == 2) asm volatile("" ::: "memory");  // (two loads per displacement: bound the batch)
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = 3 * wave + k;
+      const int yy = gy + i - D;
+      const bool rowok = yy >= 0 && yy < H;
+      // ACT == 2: channel 80-(i*9+j) is row 2-k, column 8-j of plane 2-wave; it is needed at pixel
+      // (yy, gx+p+j-4): the 9-bit row-(2-k) fields of the 12 sign words of columns gx-4 .. gx+7, three
+      // fields per register
+      unsigned pk[4] = {0u, 0u, 0u, 0u};
+      if (ACT == 2) {
+        const unsigned* row = sb + (long)(NW - 1 - wave) * cs + (long)yy * W;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int xb = gx - D + 4 * q;
+          const uint4 t = *reinterpret_cast<const uint4*>(rowok && xb >= 0 && xb < W ? row + xb : zu);
+          const unsigned wd[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int w = 4 * q + e;
+            pk[w / 3] |= ((wd[e] >> ((2 - k) * N)) & 0x1ffu) << ((w % 3) * N);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
         // 4 consecutive pixels starting at gx + (j-4): one or two ALIGNED float4 loads (gx and W are
         // multiples of 4, so an aligned block is entirely inside or outside a row) + a compile-time
         // register shift, instead of 4 bounds-checked scalar loads
-        const int yy = gy + i - D;
         const long gro = (N * N - 1 - (i * N + j)) * cs + (long)yy * W;
-        const bool rowok = yy >= 0 && yy < H;
-        const int e = j - D;                       // -4 .. 4 (compile-time after unrolling)
+        const int e = j - D;                                    // -4 .. 4 (compile-time after unrolling)
         const int blo = (e >= 0 ? e / 4 : -((3 - e) / 4)) * 4;  // 4*floor(e/4)
-        const int sh = e - blo;                    // 0..3
-        float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+        const int sh = e - blo;                                 // 0..3
         const int xlo = gx + blo, xhi = xlo + 4;
-        if (rowok && xlo >= 0 && xlo < W) {
-          const float4 t = load4(gro + xlo);
-          lo[0] = t.x, lo[1] = t.y, lo[2] = t.z, lo[3] = t.w;
-        }
-        if (sh != 0 && rowok && xhi >= 0 && xhi < W) {
-          const float4 t = load4(gro + xhi);
-          hi[0] = t.x, hi[1] = t.y, hi[2] = t.z, hi[3] = t.w;
+        const float4 tl = load4(rowok && xlo >= 0 && xlo < W, gro + xlo);
+        const float lo[4] = {tl.x, tl.y, tl.z, tl.w};
+        float hi[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sh != 0) {
+          const float4 th = load4(rowok && xhi >= 0 && xhi < W, gro + xhi);
+          hi[0] = th.x, hi[1] = th.y, hi[2] = th.z, hi[3] = th.w;
         }
 #pragma unroll
         for (int p = 0; p < PX; ++p) g[k][j][p] = (p + sh < 4) ? lo[p + sh] : hi[p + sh - 4];
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+          if (ACT == 2 && !((pk[(j + p) / 3] >> (((j + p) % 3) * N + (N - 1 - j))) & 1u)) g[k][j][p] *= slope;
+        // at most half a row shift's loads (8 x 16 B per lane) in flight at a time: more does not fit
+        // the 168-VGPR budget (3 waves per SIMD) next to g[][][]
+        if (ACT == 1 ? j % 3 == 2 : (j == 4 || j == N - 1)) asm volatile("" ::: "memory");
       }
     }
   }
@@ -332,22 +386,23 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
     if (ch + NBUF - 1 < nchunk) issue(ch + NBUF - 1);
     const float* cur = lds + (ch % NBUF) * BUF;
     const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
-    float w[2][PX + 2 * D];
-    load_window(s2, w[0]);
+    f32x4 wc[3], wn[3];
+    issue_window(s2, wc);
+    land_window(wc);
 #pragma unroll 1
     for (int c = 0; c < CC; ++c) {
       const float* sc = s2 + c * SR * SP;
       float pa[PX] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        load_window(k < 2 ? sc + (k + 1) * SP : sc + SR * SP, w[(k + 1) & 1]);  // next step (in-bounds past the end)
+        issue_window(k < 2 ? sc + (k + 1) * SP : sc + SR * SP, wn);  // next step (in-bounds past the end)
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-          for (int p = 0; p < PX; ++p) pa[p] = fmaf(g[k][j][p], w[k & 1][j + p], pa[p]);
+          for (int p = 0; p < PX; ++p) pa[p] = fmaf(g[k][j][p], CORR_WIN(wc, j + p), pa[p]);
+        land_window(wn);
+        wc[0] = wn[0], wc[1] = wn[1], wc[2] = wn[2];
       }
-#pragma unroll
-      for (int q = 0; q < PX + 2 * D; ++q) w[0][q] = w[1][q];
       *reinterpret_cast<float4*>(part + ((wave * CC + c) * 64 + lane) * PX) = make_float4(pa[0], pa[1], pa[2], pa[3]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -372,20 +427,21 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 
 inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
 
-inline int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, float slope,
-                      hipStream_t st) {
+inline int launch_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C, int H, int W,
+                      float slope, hipStream_t st) {
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B;
   dim3 grid(grid_for_tiles(tiles));
   // many tiles: 4 workgroups per CU hide each other's DMA latency, keep LDS small (2 buffers);
   // few tiles: one workgroup per CU -> deeper ring so its own DMA runs 3 chunks ahead
   if (tiles >= 768)
-    hipLaunchKernelGGL(fwd_kernel<2>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C, slope);
+    hipLaunchKernelGGL(fwd_kernel<2>, grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, 1.0f / (float)C, slope);
   else
-    hipLaunchKernelGGL(fwd_kernel<4>, grid, dim3(NT), 0, st, x1, x2, out, B, C, H, W, 1.0f / (float)C, slope);
+    hipLaunchKernelGGL(fwd_kernel<4>, grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, 1.0f / (float)C, slope);
   return af_launch_status();
 }
 
-inline int launch_bwd(const float* gout, const float* fout, float slope, const float* x1, const float* x2,
+inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign_bits, float slope, const float* x1,
+                      const float* x2,
                       float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st) {
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
@@ -393,12 +449,18 @@ inline int launch_bwd(const float* gout, const float* fout, float slope, const f
   int nsplit = 1;  // spread channel chunks over workgroups until ~1024 are in flight
   while (nsplit * 2 <= C / CC && tiles * nsplit * 2 <= 1024) nsplit *= 2;
   dim3 grid(grid_for_tiles(tiles), nsplit);
-  if (tiles >= 768)
-    hipLaunchKernelGGL(bwd_kernel<2>, grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
-                       gx1 ? 0 : 1, nmodes);
-  else
-    hipLaunchKernelGGL(bwd_kernel<4>, grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, 1.0f / (float)C,
-                       gx1 ? 0 : 1, nmodes);
+  const int act = sign_bits ? 2 : (fout ? 1 : 0);
+  const float inv_c = 1.0f / (float)C;
+  const int mb = gx1 ? 0 : 1;
+#define CORR_V2_BWD(NB, ACT)                                                                                      \
+  hipLaunchKernelGGL((bwd_kernel<NB, ACT>), grid, dim3(NT), 0, st, gout, fout, sign_bits, slope, x1, x2, gx1, gx2, \
+                     B, C, H, W, inv_c, mb, nmodes)
+  if (tiles >= 768) {
+    if (act == 2) CORR_V2_BWD(2, 2); else if (act == 1) CORR_V2_BWD(2, 1); else CORR_V2_BWD(2, 0);
+  } else {
+    if (act == 2) CORR_V2_BWD(4, 2); else if (act == 1) CORR_V2_BWD(4, 1); else CORR_V2_BWD(4, 0);
+  }
+#undef CORR_V2_BWD
   return af_launch_status();
 }
 

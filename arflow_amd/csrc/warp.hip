@@ -372,18 +372,23 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
 namespace lds_scatter {
 constexpr int TX = 32, TY = 8, NT = TX * TY;
 constexpr int WMAX = 128, HMAX = 64, NCELL = WMAX * HMAX, CCH = 4;
+static_assert(CCH == 4, "gt holds one float4 per pixel");
 
 __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restrict__ gout,
                                                           const float* __restrict__ flow, float* __restrict__ gsrc,
                                                           int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
                                                           int pad, int align, int norm) {
-  // cell c lives at cell_ptr[c + (c >> 5)]: the scan walks a lane-private run of consecutive cells, and the
-  // +1-per-32 skew keeps 64 lanes with a stride that is a multiple of 32 on distinct banks
-  __shared__ int cell_ptr[NCELL + NCELL / 32 + 1];  // counts, then running fill pointers
+  // cell c lives at halfword cell_ptr[c + (c >> 5)]: the scan walks a lane-private run of consecutive cells,
+  // and the +1-per-32 skew keeps 64 lanes with a stride that is a multiple of 32 off a common bank.
+  // 16-bit cells (a workgroup has at most 4 * 256 = 1024 list entries) halve the array: 17 KB instead of
+  // 34 KB lets 4 workgroups share a CU instead of 2 -- the kernel is latency-bound, occupancy is what hides it.
+  // Counting / filling use 32-bit LDS atomics on the containing word (1 << 16 for the upper cell; a cell
+  // never exceeds 1024, so nothing carries into its neighbour); the scan uses 16-bit loads / stores.
+  __shared__ __attribute__((aligned(4))) unsigned short cell_ptr[NCELL + NCELL / 32 + 2];  // counts, then fill pointers
   __shared__ unsigned short ne_cell[4 * NT];    // compacted non-empty cells, packed (row << 7 | col), row-major
   __shared__ unsigned short ne_beg[4 * NT + 1]; // first entry of each non-empty cell; [n] = total
   __shared__ float2 entry[4 * NT];              // (pixel index as float bits, weight)
-  __shared__ float gt[2][CCH][NT];              // staged output gradients, double-buffered
+  __shared__ float4 gt[2][NT];                  // staged output gradients (4 channels per pixel), double-buffered
   __shared__ int red[4][4];
   __shared__ int box[4];
   __shared__ int wave_tot[2][NT / 64];
@@ -429,14 +434,23 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
   const int ncell = bh * wp;
   const int per = (ncell + NT - 1) / NT;  // consecutive cells owned by one thread in the scan
   auto slot_of = [](int c) { return c + (c >> 5); };
-  for (int i = threadIdx.x; i < ncell + (ncell >> 5) + 1; i += NT) cell_ptr[i] = 0;
+  auto cell_add = [&](int c) {  // returns the cell's value before the increment
+    const int sl = slot_of(c);
+    const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(cell_ptr) + (sl >> 1), (sl & 1) ? 0x10000u : 1u);
+    return (int)((sl & 1) ? old >> 16 : old & 0xffffu);
+  };
+  {
+    unsigned* cw = reinterpret_cast<unsigned*>(cell_ptr);
+    const int nhalf = ncell + (ncell >> 5) + 1;
+    for (int i = threadIdx.x; i < (nhalf + 1) / 2; i += NT) cw[i] = 0u;
+  }
   __syncthreads();
   const int rx = t.x0 - bx0, ry = t.y0 - by0;
   const int cell[4] = {ry * wp + rx, ry * wp + rx + 1, (ry + 1) * wp + rx, (ry + 1) * wp + rx + 1};
   // 1. count contributors per cell
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (ok[k]) atomicAdd(&cell_ptr[slot_of(cell[k])], 1);
+    if (ok[k]) cell_add(cell[k]);
   __syncthreads();
   // 2. scan: entries and non-empty cells are numbered in cell order
   const int c_lo = min((int)threadIdx.x * per, ncell), c_hi = min(c_lo + per, ncell);
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
         ne_beg[basez] = (unsigned short)base;
         ++basez;
       }
-      cell_ptr[slot_of(ci)] = base;  // becomes the fill pointer
+      cell_ptr[slot_of(ci)] = (unsigned short)base;  // becomes the fill pointer
       base += c;
       if (++cc == wp) cc = 0, ++r;
     }
@@ -479,15 +493,29 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (ok[k]) {
-      const int slot = atomicAdd(&cell_ptr[slot_of(cell[k])], 1);
+      const int slot = cell_add(cell[k]);
       entry[slot] = make_float2(__int_as_float((int)threadIdx.x), wgt[k]);
     }
   __syncthreads();
-  // 4. per channel chunk: stage gout, gather per non-empty cell, one global atomic per cell and channel
+#if defined(AF_ABLATE) && AF_ABLATE == 1
+  return;
+#endif
+  // 4. per channel chunk: stage gout pixel-major (one ds_write_b128 per pixel, one ds_read_b128 per list
+  //    entry brings its 4 channels), gather per non-empty cell, one global atomic per cell and channel
   int buf = 0;
-  for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH, buf ^= 1) {
+  auto fetch = [&](int c0, float (&v)[CCH]) {
 #pragma unroll
-    for (int c = 0; c < CCH; ++c) gt[buf][c][threadIdx.x] = (c0 + c < C && inside) ? gop[(c0 + c) * os] : 0.f;
+#if defined(AF_ABLATE) && AF_ABLATE == 5
+    for (int c = 0; c < CCH; ++c) v[c] = (float)(c0 + c);
+#else
+    for (int c = 0; c < CCH; ++c) v[c] = (c0 + c < C && inside) ? gop[(c0 + c) * os] : 0.f;
+#endif
+  };
+  float nv[CCH];  // the next chunk's gradients travel while the current chunk is gathered
+  fetch(blockIdx.y * CCH, nv);
+  for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH, buf ^= 1) {
+    gt[buf][threadIdx.x] = make_float4(nv[0], nv[1], nv[2], nv[3]);
+    fetch(c0 + gridDim.y * CCH, nv);
     __syncthreads();
     for (int i = threadIdx.x; i < totalz; i += NT) {
       const int ci = ne_cell[i];
@@ -495,16 +523,41 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
       float acc[CCH];
 #pragma unroll
       for (int c = 0; c < CCH; ++c) acc[c] = 0.f;
-      for (int e = beg; e < end; ++e) {
-        const float2 en = entry[e];
-        const int pix = __float_as_int(en.x);
+      // four list entries per trip (most cells have <= 4 contributors): the entry reads go out together,
+      // then the four gradient reads -- two dependent LDS round trips per cell instead of two per entry.
+      // Slots past the end re-read the last entry with weight 0 (same sum, same order).
+#if defined(AF_ABLATE) && AF_ABLATE == 4
+      for (int e = beg; e < beg; e += 4) {
+#else
+      for (int e = beg; e < end; e += 4) {
+#endif
+        float2 en[4];
 #pragma unroll
-        for (int c = 0; c < CCH; ++c) acc[c] = fmaf(gt[buf][c][pix], en.y, acc[c]);
+        for (int u = 0; u < 4; ++u) {
+          en[u] = entry[min(e + u, end - 1)];
+          if (e + u >= end) en[u].y = 0.f;
+        }
+        float4 gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = gt[buf][__float_as_int(en[u].x)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[0] = fmaf(gv[u].x, en[u].y, acc[0]);
+          acc[1] = fmaf(gv[u].y, en[u].y, acc[1]);
+          acc[2] = fmaf(gv[u].z, en[u].y, acc[2]);
+          acc[3] = fmaf(gv[u].w, en[u].y, acc[3]);
+        }
       }
       float* d = gp + (long)c0 * ss + (long)(by0 + (ci >> 7)) * Ws + bx0 + (ci & 127);
 #pragma unroll
       for (int c = 0; c < CCH; ++c)
+#if defined(AF_ABLATE) && (AF_ABLATE == 2 || AF_ABLATE == 5)
+        if (c0 + c < C && acc[c] == 12345.678f) d[c * ss] = acc[c];
+#elif defined(AF_ABLATE) && AF_ABLATE == 3
+        if (c0 + c < C) d[c * ss] = acc[c];
+#else
         if (c0 + c < C) atomicAdd(d + c * ss, acc[c]);
+#endif
     }
     // gt is double-buffered: the next chunk stages into the other buffer; its barrier orders this chunk's
     // reads before this buffer is overwritten two chunks later

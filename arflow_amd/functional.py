@@ -112,19 +112,25 @@ class CorrelationFunction(torch.autograd.Function):
         x1, x2 = x1.contiguous(), x2.contiguous()
         Wk = W + wp
         out = torch.empty(B, (2 * d + 1) ** 2, H, Wk, device=x1.device, dtype=torch.float32)
+        # fused LeakyReLU: the backward selects the derivative from 12 bytes of sign words per pixel (fast
+        # path) instead of keeping and re-reading the 324-byte volume; shapes without the fast path keep `out`
+        planes = _lib.load().arflow_corr_sign_planes(C, Wk, d) if slope != 1.0 else 0
+        sign = torch.empty(B, planes, H, Wk, device=x1.device, dtype=torch.int32) if planes else None
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), B, C, H, Wk, d, slope, _stream(), key=(B, C, H, Wk, d))
+            _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), _p(sign), B, C, H, Wk, d, slope, _stream(),
+                  key=(B, C, H, Wk, d))
         if slope != 1.0:
-            ctx.save_for_backward(x1, x2, out)  # the sign of the output selects the LeakyReLU derivative
+            ctx.save_for_backward(x1, x2, sign if planes else out)
         else:
             ctx.save_for_backward(x1, x2)
-        ctx.d, ctx.slope, ctx.w, ctx.wp = d, slope, W, wp
+        ctx.d, ctx.slope, ctx.w, ctx.wp, ctx.planes = d, slope, W, wp, planes
         return out[..., :W].contiguous() if wp else out
 
     @staticmethod
     def backward(ctx, gout):
         x1, x2 = ctx.saved_tensors[:2]
-        fout = ctx.saved_tensors[2] if ctx.slope != 1.0 else None
+        act = ctx.saved_tensors[2] if ctx.slope != 1.0 else None
+        fout, sign = (None, act) if ctx.planes else (act, None)
         B, C, H, Wk = x1.shape
         if ctx.wp:
             gout = torch.nn.functional.pad(gout, (0, ctx.wp))
@@ -132,8 +138,8 @@ class CorrelationFunction(torch.autograd.Function):
         g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
         with torch.cuda.device_of(x1):
-            _call('arflow_corr_bwd', _p(gout), _p(fout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, Wk, ctx.d, ctx.slope,
-                  _stream(), key=(B, C, H, Wk, ctx.d, fout is not None))
+            _call('arflow_corr_bwd', _p(gout), _p(fout), _p(sign), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, Wk, ctx.d,
+                  ctx.slope, _stream(), key=(B, C, H, Wk, ctx.d, act is not None))
         if ctx.wp:
             g1 = None if g1 is None else g1[..., :ctx.w].contiguous()
             g2 = None if g2 is None else g2[..., :ctx.w].contiguous()

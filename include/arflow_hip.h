@@ -67,19 +67,25 @@ const char* arflow_strerror(int code);
  * Replaces correlation_cuda.forward (correlation_cuda.cc:10-87), Correlation.forward
  * (models/correlation_native.py:13-23) and compute_cost_volume (models/uflow_model.py:53-92).
  * x1,x2: [B,C,H,W]; out: [B,(2d+1)^2,H,W]; 1 <= max_disp. */
-int arflow_corr_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W,
-                    int max_disp, float negative_slope, arflow_stream_t stream);
+int arflow_corr_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C, int H,
+                    int W, int max_disp, float negative_slope, arflow_stream_t stream);
 /* negative_slope: fused LeakyReLU on the cost volume, out = v > 0 ? v : negative_slope * v -- the
  * activation every caller applies right after the correlation (models/pwclite.py:183-184,
- * models/uflow_model.py:180); 1.0f = plain cost volume. */
+ * models/uflow_model.py:180); 1.0f = plain cost volume.
+ * sign_bits (nullable): compact record of `v > 0` for the backward, [B, arflow_corr_sign_planes(), H, W]
+ * 32-bit words: bit (i % 3) * 9 + j of plane i / 3 belongs to channel i * 9 + j.  Only produced by the
+ * max_disp = 4 fast path: asking for it when arflow_corr_sign_planes(C, W, max_disp) == 0 is ARFLOW_EPARAM. */
+int arflow_corr_sign_planes(int C, int W, int max_disp); /* 3, or 0 if this shape has no sign_bits */
 
 /* Gradients of the above (correlation_cuda.backward, correlation_cuda.cc:89-167; kernels
  * correlation_cuda_kernel.cu:116-300).  gx1 / gx2 may be NULL to skip that gradient. */
-int arflow_corr_bwd(const float* gout, const float* out, const float* x1, const float* x2, float* gx1,
-                    float* gx2, int B, int C, int H, int W, int max_disp, float negative_slope,
-                    arflow_stream_t stream);
-/* With negative_slope != 1 the forward OUTPUT must be passed as `out` (its sign selects the LeakyReLU
- * derivative, exactly as torch's in-place leaky_relu backward does); otherwise `out` may be NULL. */
+int arflow_corr_bwd(const float* gout, const float* out, const unsigned* sign_bits, const float* x1,
+                    const float* x2, float* gx1, float* gx2, int B, int C, int H, int W, int max_disp,
+                    float negative_slope, arflow_stream_t stream);
+/* With negative_slope != 1 the LeakyReLU derivative is selected per element by the forward's sign_bits
+ * (12 bytes per pixel instead of re-reading the 324-byte volume) or, when sign_bits is NULL, by the sign
+ * of the forward OUTPUT passed as `out` (as torch's in-place leaky_relu backward does; needs
+ * negative_slope > 0).  One of the two must be given; with negative_slope == 1 both may be NULL. */
 
 /* ---- bilinear warp ----------------------------------------------------------------------------
  * out[b,c,y,x] = bilinear(src[b,c], x + flow[b,0,y,x], y + flow[b,1,y,x]) with torch grid_sample

@@ -50,12 +50,14 @@ def test_prototype_arity_matches_header():
 
 def test_argument_errors_without_gpu(lib):
     # validation happens before any launch, so these are safe on a CPU-only host
-    assert lib.arflow_abi_version() == 2
-    assert lib.arflow_corr_fwd(None, None, None, 1, 1, 1, 1, 4, 1.0, None) == -1001
+    assert lib.arflow_abi_version() == 3
+    assert lib.arflow_corr_fwd(None, None, None, None, 1, 1, 1, 1, 4, 1.0, None) == -1001
     one = ctypes.c_void_p(16)
-    assert lib.arflow_corr_fwd(one, one, one, 0, 1, 1, 1, 4, 1.0, None) == -1002
-    assert lib.arflow_corr_fwd(one, one, one, 1, 1, 1, 1, 0, 1.0, None) == -1003
-    assert lib.arflow_corr_bwd(one, None, one, one, one, one, 1, 1, 1, 1, 4, 0.1, None) == -1001  # fused LeakyReLU needs `out`
+    assert lib.arflow_corr_fwd(one, one, one, None, 0, 1, 1, 1, 4, 1.0, None) == -1002
+    assert lib.arflow_corr_fwd(one, one, one, None, 1, 1, 1, 1, 0, 1.0, None) == -1003
+    assert lib.arflow_corr_bwd(one, None, None, one, one, one, one, 1, 1, 1, 1, 4, 0.1, None) == -1001  # fused LeakyReLU needs `out` or sign_bits
+    assert lib.arflow_corr_fwd(one, one, one, one, 1, 1, 1, 1, 4, 0.1, None) == -1003  # no sign_bits off the fast path
+    assert lib.arflow_corr_sign_planes(32, 160, 4) == 3 and lib.arflow_corr_sign_planes(32, 10, 4) == 0
     assert lib.arflow_warp_fwd(one, one, one, None, 1, 1, 4, 4, 4, 4, 32, 7, 1, 0, None) == -1003
     assert lib.arflow_warp_fwd(one, one, one, None, 1, 1, 4, 4, 4, 4, 3, 0, 1, 0, None) == -1002
     assert lib.arflow_census_fwd(one, one, None, one, None, None, 1, 8, 8, 4, None) == -1003

@@ -33,7 +33,7 @@ def cu(t):
 def test_library_loaded_and_no_fallback():
     from arflow_amd import _lib, functional
     lib = _lib.load()
-    assert lib.arflow_abi_version() == 2
+    assert lib.arflow_abi_version() == _lib.ABI_VERSION
     with pytest.raises(_lib.ArflowHipError):
         functional.correlation(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4))  # CPU tensor must raise
 
@@ -78,7 +78,8 @@ def test_correlation_vs_oracle(AF, oracle, shape):
 def test_correlation_fused_leaky_relu(AF, oracle):
     """corr + LeakyReLU(0.1) fused in the kernel == leaky_relu(oracle corr), forward and both gradients."""
     gen = torch.Generator().manual_seed(77)
-    for B, C, H, W in ((2, 32, 24, 40), (1, 5, 9, 11)):
+    # fast path with sign words (aligned, ragged tiles, several tile columns), padded width, generic path
+    for B, C, H, W in ((2, 32, 24, 40), (1, 8, 20, 36), (2, 4, 9, 68), (1, 8, 6, 10), (1, 5, 9, 11)):
         x1 = torch.randn(B, C, H, W, generator=gen)
         x2 = torch.randn(B, C, H, W, generator=gen)
         go = torch.randn(B, 81, H, W, generator=gen)
@@ -92,6 +93,31 @@ def test_correlation_fused_leaky_relu(AF, oracle):
         # a pre-activation within rounding of 0 may pick the other branch: compare away from it
         assert_close(g1, r1, 1e-5, 1e-4, 'fused leaky gx1')
         assert_close(g2, r2, 1e-5, 1e-4, 'fused leaky gx2')
+
+
+def test_correlation_bwd_derivative_from_output(AF, oracle):
+    """arflow_corr_bwd on the fast path WITHOUT sign words: the LeakyReLU derivative is taken from the
+    sign of the forward output (`out` argument), like torch's in-place leaky_relu backward."""
+    from arflow_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(78)
+    B, C, H, W = 2, 8, 20, 36
+    x1, x2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+    go = torch.randn(B, 81, H, W, generator=gen)
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(oracle.correlation(a, b, 4), 0.1)
+    r1, r2 = torch.autograd.grad(ref, [a, b], go)
+    x1c, x2c, goc = cu(x1), cu(x2), cu(go)
+    out = torch.empty(B, 81, H, W, device='cuda')
+    g1, g2 = torch.empty_like(x1c), torch.empty_like(x2c)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.arflow_corr_sign_planes(C, W, 4) == 3
+    _lib.check(lib.arflow_corr_fwd(x1c.data_ptr(), x2c.data_ptr(), out.data_ptr(), None, B, C, H, W, 4, 0.1, st), 'fwd')
+    _lib.check(lib.arflow_corr_bwd(goc.data_ptr(), out.data_ptr(), None, x1c.data_ptr(), x2c.data_ptr(), g1.data_ptr(),
+                                   g2.data_ptr(), B, C, H, W, 4, 0.1, st), 'bwd')
+    assert_close(out, ref, 1e-6, 1e-5, 'fwd')
+    assert_close(g1, r1, 1e-5, 1e-4, 'gx1 via out')
+    assert_close(g2, r2, 1e-5, 1e-4, 'gx2 via out')
 
 
 def test_correlation_module_signature(AF):

@@ -36,6 +36,8 @@ def timeit(fn, iters):
 
 
 def main():
+    if os.environ.get('ARFLOW_LIB_PATH'):  # ablation builds (tools only)
+        _lib.LIB_PATH = os.environ['ARFLOW_LIB_PATH']
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--filter', default='')
@@ -63,7 +65,7 @@ def main():
         print('%-22s %-26s %9.1f us %9.1f GB/s  %5.1f%% of HBM peak' % (name, list(shape), us, gbs, 100 * gbs / HBM_PEAK_GBS), flush=True)
 
     def want(n):
-        return args.filter in n
+        return any(f in n for f in args.filter.split('|'))
 
     for C, h, w in levels:
         x1 = torch.randn(B2, C, h, w, device=dev, generator=g)
@@ -74,10 +76,12 @@ def main():
         fl = 2.0 * torch.randn(B2, 2, h, w, device=dev, generator=g)
         wout = torch.empty_like(x1)
         gfl = torch.empty_like(fl)
-        if want('corr_fwd'):
-            rec('arflow_corr_fwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_fwd(p(x1), p(x2), p(out), B2, C, h, w, 4, 0.1, s), args.iters))
+        planes = lib.arflow_corr_sign_planes(C, w, 4)
+        sign = torch.zeros(B2, planes, h, w, device=dev, dtype=torch.int32) if planes else None
+        if want('corr_fwd') or want('corr_bwd'):
+            rec('arflow_corr_fwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_fwd(p(x1), p(x2), p(out), p(sign), B2, C, h, w, 4, 0.1, s), args.iters))
         if want('corr_bwd'):
-            rec('arflow_corr_bwd', (B2, C, h, w, 4, True), timeit(lambda: lib.arflow_corr_bwd(p(go), p(out), p(x1), p(x2), p(g1), p(g2), B2, C, h, w, 4, 0.1, s), args.iters))
+            rec('arflow_corr_bwd', (B2, C, h, w, 4, True), timeit(lambda: lib.arflow_corr_bwd(p(go), None if planes else p(out), p(sign), p(x1), p(x2), p(g1), p(g2), B2, C, h, w, 4, 0.1, s), args.iters))
         if want('warp_fwd'):
             rec('arflow_warp_fwd', (B2, C, h, w), timeit(lambda: lib.arflow_warp_fwd(p(x2), p(fl), p(wout), None, B2, C, h, w, h, w, 2 * h * w, 0, 1, 0, s), args.iters))
         if want('warp_bwd'):
