@@ -1,0 +1,258 @@
+// Feature normalisation in front of the cost volume ("next" rank 1) for gfx950.
+// Reference arithmetic: normalize_features of models/pwclite_uflow.py:30-38 (moments of the
+// channel-concatenated pair) and of models/uflow_model.py:8-50 as PWCFlow calls it (:167-172: per-tensor
+// moments over (C,H,W), averaged across the two images, centre + normalise).  Both are
+//     y_i = (x_i - mu) / sqrt(var + 1e-16),   i = 1, 2,
+// with one (mu, var) per sample:
+//     JOINT:  mu = sum(x1, x2) / 2n,          var = sum((x - mu)^2 over both) / (2n - 1)
+//     AVG:    mu = (m1 + m2) / 2,             var = (v1 + v2) / 2,   v_i = sum((x_i - m_i)^2) / (n - 1)
+//
+// In eager PyTorch this is ~14 launches forward and ~30 backward per pyramid level, each a full pass
+// over the feature tensors.  Here: forward = one moment pass (float4 loads, fp32 per-thread partials
+// over <= 64 values, double from the wave reduction on -- sum(x^2) - sum(x)^2/n is then exact to fp32
+// for any mean / spread ratio) + one apply pass; backward = one pass for the two sums the chain rule
+// needs + one apply pass.  HBM-bound: 3 reads + 1 write of each tensor forward, 4 reads + 1 write backward.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256, VPT = 16;  // floats per thread per tensor and trip (4 float4)
+
+// sum over the block of NV doubles per thread; result in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum_f64(double (&v)[NV], double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) scratch[k * (NT / 64) + wave] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double s = 0.0;
+      for (int w = 0; w < NT / 64; ++w) s += scratch[k * (NT / 64) + w];
+      v[k] = s;
+    }
+  }
+}
+
+struct Moments {
+  float m1, m2, mu, rstd, var;
+};
+
+// (sum x1, sum x1^2, sum x2, sum x2^2) -> the sample's statistics
+__device__ __forceinline__ Moments moments_of(const double* a, long n, int mode) {
+  const double dn = (double)n;
+  const double m1 = a[0] / dn, m2 = a[2] / dn;
+  double mu, var;
+  if (mode == ARFLOW_FEATNORM_JOINT) {
+    const double N = 2.0 * dn;
+    mu = (a[0] + a[2]) / N;
+    var = ((a[1] + a[3]) - N * mu * mu) / (N - 1.0);
+  } else {
+    mu = 0.5 * (m1 + m2);
+    var = 0.5 * ((a[1] - dn * m1 * m1) + (a[3] - dn * m2 * m2)) / (dn - 1.0);
+  }
+  var = var > 0.0 ? var : 0.0;
+  Moments m;
+  m.m1 = (float)m1, m.m2 = (float)m2, m.mu = (float)mu, m.var = (float)var;
+  m.rstd = 0.f;
+  return m;
+}
+
+// grid (blocks per sample, B).  acc[b] += (sum x1, sum x1^2, sum x2, sum x2^2) of this block's slice.
+__global__ __launch_bounds__(NT) void moment_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                    double* __restrict__ acc, long n) {
+  __shared__ double scratch[4 * (NT / 64)];
+  const int b = blockIdx.y;
+  const float* p1 = x1 + (long)b * n;
+  const float* p2 = x2 + (long)b * n;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  const long n4 = (n % 4 == 0) ? n / 4 : 0;  // float4 part (rows are 16-byte aligned only when n % 4 == 0)
+  for (long i0 = (long)blockIdx.x * NT * (VPT / 4); i0 < n4; i0 += (long)gridDim.x * NT * (VPT / 4)) {
+    float a1 = 0.f, q1 = 0.f, a2 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT / 4; ++k) {
+      const long i = i0 + (long)k * NT + threadIdx.x;
+      if (i < n4) {
+        const float4 u = reinterpret_cast<const float4*>(p1)[i];
+        const float4 v = reinterpret_cast<const float4*>(p2)[i];
+        a1 += (u.x + u.y) + (u.z + u.w);
+        q1 = fmaf(u.x, u.x, fmaf(u.y, u.y, fmaf(u.z, u.z, fmaf(u.w, u.w, q1))));
+        a2 += (v.x + v.y) + (v.z + v.w);
+        q2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, q2))));
+      }
+    }
+    s[0] += (double)a1, s[1] += (double)q1, s[2] += (double)a2, s[3] += (double)q2;
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {  // unaligned sizes
+    const float u = p1[i], v = p2[i];
+    s[0] += (double)u, s[1] += (double)u * (double)u, s[2] += (double)v, s[3] += (double)v * (double)v;
+  }
+  block_sum_f64<4>(s, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(acc + 4 * b + k, s[k]);
+  }
+}
+
+// y_i = (x_i - mu) / std; block (0, b) records (m1, m2, mu, std) for the backward.
+__global__ __launch_bounds__(NT) void apply_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                   float* __restrict__ y1, float* __restrict__ y2,
+                                                   const double* __restrict__ acc, float* __restrict__ stats, long n,
+                                                   int mode) {
+  const int b = blockIdx.y;
+  const Moments m = moments_of(acc + 4 * b, n, mode);
+  const float sd = sqrtf(m.var + 1e-16f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float* st = stats + 4 * b;
+    st[0] = m.m1, st[1] = m.m2, st[2] = m.mu, st[3] = sd;
+  }
+  const float* p1 = x1 + (long)b * n;
+  const float* p2 = x2 + (long)b * n;
+  float* o1 = y1 + (long)b * n;
+  float* o2 = y2 + (long)b * n;
+  const long n4 = (n % 4 == 0) ? n / 4 : 0;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+    const float4 u = reinterpret_cast<const float4*>(p1)[i];
+    const float4 v = reinterpret_cast<const float4*>(p2)[i];
+    reinterpret_cast<float4*>(o1)[i] =
+        make_float4((u.x - m.mu) / sd, (u.y - m.mu) / sd, (u.z - m.mu) / sd, (u.w - m.mu) / sd);
+    reinterpret_cast<float4*>(o2)[i] =
+        make_float4((v.x - m.mu) / sd, (v.y - m.mu) / sd, (v.z - m.mu) / sd, (v.w - m.mu) / sd);
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    o1[i] = (p1[i] - m.mu) / sd;
+    o2[i] = (p2[i] - m.mu) / sd;
+  }
+}
+
+// acc[b] += (sum g, sum g (x - mu)) over both tensors (entries 0, 1)
+__global__ __launch_bounds__(NT) void bwd_sum_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                     const float* __restrict__ x1, const float* __restrict__ x2,
+                                                     const float* __restrict__ stats, double* __restrict__ acc,
+                                                     long n) {
+  __shared__ double scratch[2 * (NT / 64)];
+  const int b = blockIdx.y;
+  const float mu = stats[4 * b + 2];
+  const long o = (long)b * n;
+  double s[2] = {0.0, 0.0};
+  const long n4 = (n % 4 == 0) ? n / 4 : 0;
+  for (long i0 = (long)blockIdx.x * NT * (VPT / 4); i0 < n4; i0 += (long)gridDim.x * NT * (VPT / 4)) {
+    float sg = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT / 4; ++k) {
+      const long i = i0 + (long)k * NT + threadIdx.x;
+      if (i < n4) {
+        const float4 ga = reinterpret_cast<const float4*>(g1 + o)[i], xa = reinterpret_cast<const float4*>(x1 + o)[i];
+        const float4 gb = reinterpret_cast<const float4*>(g2 + o)[i], xb = reinterpret_cast<const float4*>(x2 + o)[i];
+        sg += ((ga.x + ga.y) + (ga.z + ga.w)) + ((gb.x + gb.y) + (gb.z + gb.w));
+        sq = fmaf(ga.x, xa.x - mu, fmaf(ga.y, xa.y - mu, fmaf(ga.z, xa.z - mu, fmaf(ga.w, xa.w - mu, sq))));
+        sq = fmaf(gb.x, xb.x - mu, fmaf(gb.y, xb.y - mu, fmaf(gb.z, xb.z - mu, fmaf(gb.w, xb.w - mu, sq))));
+      }
+    }
+    s[0] += (double)sg, s[1] += (double)sq;
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const float ga = g1[o + i], gb = g2[o + i];
+    s[0] += (double)ga + (double)gb;
+    s[1] += (double)ga * (double)(x1[o + i] - mu) + (double)gb * (double)(x2[o + i] - mu);
+  }
+  block_sum_f64<2>(s, scratch);
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + 4 * b, s[0]);
+    atomicAdd(acc + 4 * b + 1, s[1]);
+  }
+}
+
+// With r = 1/std, G = sum g, Q = sum g (x - mu) (both tensors):
+//   JOINT: dx = r g - r G / N - r^3 Q (x - mu) / (N - 1),           N = 2n
+//   AVG:   dx_i = r g - r G / (2n) - r^3 Q (x - m_i) / (2 (n - 1))
+__global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                       const float* __restrict__ x1, const float* __restrict__ x2,
+                                                       const float* __restrict__ stats, const double* __restrict__ acc,
+                                                       float* __restrict__ d1, float* __restrict__ d2, long n,
+                                                       int mode) {
+  const int b = blockIdx.y;
+  const float* st = stats + 4 * b;
+  const double r = 1.0 / (double)st[3];
+  const double G = acc[4 * b], Q = acc[4 * b + 1], dn = (double)n;
+  const float rf = (float)r;
+  const float cg = (float)(r * G / (2.0 * dn));
+  const float cq = (float)(mode == ARFLOW_FEATNORM_JOINT ? r * r * r * Q / (2.0 * dn - 1.0) : r * r * r * Q / (2.0 * (dn - 1.0)));
+  const float c1 = mode == ARFLOW_FEATNORM_JOINT ? st[2] : st[0], c2 = mode == ARFLOW_FEATNORM_JOINT ? st[2] : st[1];
+  const long o = (long)b * n;
+  auto f = [&](float g, float x, float c) { return fmaf(rf, g, -cg) - cq * (x - c); };
+  const long n4 = (n % 4 == 0) ? n / 4 : 0;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+    if (d1) {
+      const float4 g = reinterpret_cast<const float4*>(g1 + o)[i], x = reinterpret_cast<const float4*>(x1 + o)[i];
+      reinterpret_cast<float4*>(d1 + o)[i] = make_float4(f(g.x, x.x, c1), f(g.y, x.y, c1), f(g.z, x.z, c1), f(g.w, x.w, c1));
+    }
+    if (d2) {
+      const float4 g = reinterpret_cast<const float4*>(g2 + o)[i], x = reinterpret_cast<const float4*>(x2 + o)[i];
+      reinterpret_cast<float4*>(d2 + o)[i] = make_float4(f(g.x, x.x, c2), f(g.y, x.y, c2), f(g.z, x.z, c2), f(g.w, x.w, c2));
+    }
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    if (d1) d1[o + i] = f(g1[o + i], x1[o + i], c1);
+    if (d2) d2[o + i] = f(g2[o + i], x2[o + i], c2);
+  }
+}
+
+// enough workgroups to fill the chip (~2048) without slicing a sample finer than one trip per block
+inline unsigned blocks_per_sample(int B, long n, int floats_per_block) {
+  long nb = (n + floats_per_block - 1) / floats_per_block;
+  const long want = (2048 + B - 1) / B;
+  if (nb > want) nb = want;
+  return (unsigned)(nb < 1 ? 1 : nb);
+}
+
+}  // namespace
+
+extern "C" int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, float* y2, double* acc, float* stats,
+                                   int B, long n, int mode, arflow_stream_t stream) {
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE_PTR(y1);
+  AF_REQUIRE_PTR(y2);
+  AF_REQUIRE_PTR(acc);
+  AF_REQUIRE_PTR(stats);
+  AF_REQUIRE(B > 0 && B <= 65535 && n >= 2, ARFLOW_ESHAPE);
+  AF_REQUIRE(mode == ARFLOW_FEATNORM_JOINT || mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 4 * (size_t)B, st);
+  if (e != hipSuccess) return af_hip_status(e);
+  hipLaunchKernelGGL(moment_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, x1, x2, acc, n);
+  hipLaunchKernelGGL(apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, x1, x2, y1, y2, acc, stats, n,
+                     mode);
+  return af_launch_status();
+}
+
+extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float* x1, const float* x2,
+                                   const float* stats, double* acc, float* gx1, float* gx2, int B, long n, int mode,
+                                   arflow_stream_t stream) {
+  AF_REQUIRE_PTR(g1);
+  AF_REQUIRE_PTR(g2);
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE_PTR(stats);
+  AF_REQUIRE_PTR(acc);
+  AF_REQUIRE(B > 0 && B <= 65535 && n >= 2, ARFLOW_ESHAPE);
+  AF_REQUIRE(mode == ARFLOW_FEATNORM_JOINT || mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
+  if (!gx1 && !gx2) return ARFLOW_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 4 * (size_t)B, st);
+  if (e != hipSuccess) return af_hip_status(e);
+  hipLaunchKernelGGL(bwd_sum_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
+                     n);
+  hipLaunchKernelGGL(bwd_apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
+                     gx1, gx2, n, mode);
+  return af_launch_status();
+}

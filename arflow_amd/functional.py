@@ -118,7 +118,7 @@ class CorrelationFunction(torch.autograd.Function):
         sign = torch.empty(B, planes, H, Wk, device=x1.device, dtype=torch.int32) if planes else None
         with torch.cuda.device_of(x1):
             _call('arflow_corr_fwd', _p(x1), _p(x2), _p(out), _p(sign), B, C, H, Wk, d, slope, _stream(),
-                  key=(B, C, H, Wk, d))
+                  key=(B, C, H, Wk, d, planes))
         if slope != 1.0:
             ctx.save_for_backward(x1, x2, sign if planes else out)
         else:
@@ -139,7 +139,7 @@ class CorrelationFunction(torch.autograd.Function):
         g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
         with torch.cuda.device_of(x1):
             _call('arflow_corr_bwd', _p(gout), _p(fout), _p(sign), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, Wk, ctx.d,
-                  ctx.slope, _stream(), key=(B, C, H, Wk, ctx.d, act is not None))
+                  ctx.slope, _stream(), key=(B, C, H, Wk, ctx.d, 0 if act is None else (ctx.planes or (2 * ctx.d + 1) ** 2)))
         if ctx.wp:
             g1 = None if g1 is None else g1[..., :ctx.w].contiguous()
             g2 = None if g2 is None else g2[..., :ctx.w].contiguous()
@@ -150,6 +150,52 @@ def correlation(x1, x2, max_displacement=4, negative_slope=1.0):
     """Cost volume, optionally with the LeakyReLU every caller applies right after it fused into the
     kernel's store stage (and its derivative into the backward's load stage)."""
     return CorrelationFunction.apply(x1, x2, max_displacement, negative_slope)
+
+
+# ------------------------------------------------------------------------------------------------
+FEATNORM = {'joint': 0, 'avg': 1}
+
+
+class FeatureNormFunction(torch.autograd.Function):
+    """(x1, x2) -> ((x1 - mu) / std, (x2 - mu) / std) with per-sample moments over both tensors:
+    normalize_features of models/pwclite_uflow.py:30-38 ('joint') and of models/uflow_model.py:8-50 as
+    PWCFlow calls it ('avg').  Two launches forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, mode):
+        _need_gpu(x1, x2)
+        if x1.shape != x2.shape or x1.dim() < 2:
+            raise ValueError('feature normalisation expects two tensors of equal shape [B, ...]')
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B = x1.shape[0]
+        n = x1[0].numel()
+        y1, y2 = torch.empty_like(x1), torch.empty_like(x2)
+        acc = torch.empty(4 * B, device=x1.device, dtype=torch.float64)
+        stats = torch.empty(B, 4, device=x1.device, dtype=torch.float32)
+        with torch.cuda.device_of(x1):
+            _call('arflow_featnorm_fwd', _p(x1), _p(x2), _p(y1), _p(y2), _p(acc), _p(stats), B, n, mode, _stream(),
+                  key=(B, n))
+        ctx.save_for_backward(x1, x2, stats)
+        ctx.mode = mode
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x1, x2, stats = ctx.saved_tensors
+        B = x1.shape[0]
+        n = x1[0].numel()
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        d1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        d2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        acc = torch.empty(4 * B, device=x1.device, dtype=torch.float64)
+        with torch.cuda.device_of(x1):
+            _call('arflow_featnorm_bwd', _p(g1), _p(g2), _p(x1), _p(x2), _p(stats), _p(acc), _p(d1), _p(d2), B, n,
+                  ctx.mode, _stream(), key=(B, n))
+        return d1, d2, None
+
+
+def normalize_pair(x1, x2, mode='joint'):
+    return FeatureNormFunction.apply(x1, x2, FEATNORM[mode])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as AF
 from ..correlation import Correlation
 from ..warp_utils import flow_warp
 from .blocks import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, FlowEstimatorReduce, deconv,
@@ -10,7 +11,11 @@ from .blocks import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, FlowE
 
 
 def normalize_features(features_list):
-    """models/pwclite_uflow.py:30-38 -- per-sample moments of the channel-concatenated pair."""
+    """models/pwclite_uflow.py:30-38 -- per-sample moments of the channel-concatenated pair.  The pair the
+    model normalises (two tensors of equal shape) runs as one fused HIP op; other list shapes keep the
+    tensor expression."""
+    if len(features_list) == 2 and features_list[0].shape == features_list[1].shape:
+        return list(AF.normalize_pair(features_list[0], features_list[1], 'joint'))
     n = sum(f[0].numel() for f in features_list)
     s1 = sum(f.sum(dim=(-3, -2, -1), keepdim=True) for f in features_list)
     mean = s1 / n

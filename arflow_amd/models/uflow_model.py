@@ -4,13 +4,17 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as func
 
+from .. import functional as AF
 from .. import uflow_utils
 from ..correlation import compute_cost_volume
 from .blocks import init_conv_weights, pair_batches
 
 
 def normalize_features(feature_list, normalize, center, moments_across_channels, moments_across_images):
-    """models/uflow_model.py:8-50."""
+    """models/uflow_model.py:8-50.  The configuration PWCFlow uses (:167-172) runs as one fused HIP op."""
+    if (normalize and center and moments_across_channels and moments_across_images and len(feature_list) == 2
+            and feature_list[0].shape == feature_list[1].shape):
+        return list(AF.normalize_pair(feature_list[0], feature_list[1], 'avg'))
     dim = [1, 2, 3] if moments_across_channels else [2, 3]
     means = [f.mean(dim=dim, keepdim=True) for f in feature_list]
     vars_ = [f.var(dim=dim, keepdim=True) for f in feature_list]

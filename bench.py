@@ -61,12 +61,19 @@ def algorithmic_bytes(name, shape):
     """Compulsory HBM bytes of one launch (each input read once, each output written once, fp32):
     SURVEY section 8(d).  `shape` is the tuple recorded by arflow_amd.functional for the call."""
     if name == 'arflow_corr_fwd':
-        B, C, H, W, d = shape
-        return 4 * B * H * W * (2 * C + (2 * d + 1) ** 2)
+        B, C, H, W, d = shape[:5]
+        act = shape[5] if len(shape) > 5 else 0  # fused LeakyReLU: sign words written per pixel
+        return 4 * B * H * W * (2 * C + (2 * d + 1) ** 2 + act)
     if name == 'arflow_corr_bwd':
         B, C, H, W, d = shape[:5]
-        fused = len(shape) > 5 and shape[5]  # fused LeakyReLU: the forward output is read as well
-        return 4 * B * H * W * ((2 * d + 1) ** 2 * (2 if fused else 1) + 4 * C)
+        act = int(shape[5]) if len(shape) > 5 else 0  # fused LeakyReLU: 3 sign words (fast path) or the 81-ch output read per pixel
+        return 4 * B * H * W * ((2 * d + 1) ** 2 + act + 4 * C)
+    if name == 'arflow_featnorm_fwd':
+        B, n = shape
+        return 4 * B * n * 4  # two tensors in, two out (the second read of the inputs is not compulsory)
+    if name == 'arflow_featnorm_bwd':
+        B, n = shape
+        return 4 * B * n * 6  # g1, g2, x1, x2 in; gx1, gx2 out
     if name == 'arflow_warp_fwd':
         B, C, H, W = shape
         return 4 * B * H * W * (2 * C + 2)

@@ -27,7 +27,8 @@ def oracle_ops(model):
     import arflow_amd.models.uflow_model as mum
     saved = [(mp, 'flow_warp', mp.flow_warp), (mpu, 'flow_warp', mpu.flow_warp),
              (mum, 'compute_cost_volume', mum.compute_cost_volume),
-             (mum.uflow_utils, 'resample_flow', mum.uflow_utils.resample_flow)]
+             (mum.uflow_utils, 'resample_flow', mum.uflow_utils.resample_flow),
+             (mpu, 'normalize_features', mpu.normalize_features), (mum, 'normalize_features', mum.normalize_features)]
     old_corr = getattr(model, 'corr', None)
     try:
         mp.flow_warp = O.flow_warp
@@ -35,6 +36,8 @@ def oracle_ops(model):
         mum.compute_cost_volume = lambda a, b, max_displacement, negative_slope=1.0: OracleCorrelation(
             max_displacement)(a, b, negative_slope)
         mum.uflow_utils.resample_flow = lambda src, flow: O.resample(src, O.flow_to_warp(flow))
+        mpu.normalize_features = O.normalize_features_joint
+        mum.normalize_features = O.normalize_features_uflow
         if old_corr is not None:
             model.corr = OracleCorrelation(4)
         yield model

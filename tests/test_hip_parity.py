@@ -120,6 +120,48 @@ def test_correlation_bwd_derivative_from_output(AF, oracle):
     assert_close(g2, r2, 1e-5, 1e-4, 'gx2 via out')
 
 
+def test_feature_normalisation_golden(golden, AF):
+    """Both normalize_features variants against the reference's outputs (tests/golden/aux.npz)."""
+    g = golden('aux')
+    a, b = AF.normalize_pair(cu(g['f1']), cu(g['f2']), 'joint')
+    assert_close(a, g['nj_1'], 2e-6, 1e-5, 'joint norm 1')
+    assert_close(b, g['nj_2'], 2e-6, 1e-5, 'joint norm 2')
+    c, d = AF.normalize_pair(cu(g['f1']), cu(g['f2']), 'avg')
+    assert_close(c, g['nu_1'], 2e-6, 1e-5, 'uflow norm 1')
+    assert_close(d, g['nu_2'], 2e-6, 1e-5, 'uflow norm 2')
+
+
+@pytest.mark.parametrize('mode', ['joint', 'avg'])
+@pytest.mark.parametrize('shape,offset', [((3, 32, 24, 40), 0.0), ((2, 8, 9, 11), 0.3), ((2, 32, 48, 80), 25.0),
+                                          ((1, 3, 1, 2), -1.0)])
+def test_feature_normalisation_vs_oracle(AF, oracle, mode, shape, offset):
+    """Forward and both gradients against the oracle (torch autograd of the reference expression), on
+    aligned / unaligned sizes, and with a mean 25x the spread (the moment sums must not cancel)."""
+    gen = torch.Generator().manual_seed(21)
+    x1 = torch.randn(*shape, generator=gen) + offset
+    x2 = 0.5 * torch.randn(*shape, generator=gen) + 1.5 * offset
+    g1, g2 = torch.randn(*shape, generator=gen), torch.randn(*shape, generator=gen)
+    fn = oracle.normalize_features_joint if mode == 'joint' else oracle.normalize_features_uflow
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    r1, r2 = fn([a, b])
+    ra, rb = torch.autograd.grad([r1, r2], [a, b], [g1, g2])
+    ac, bc = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
+    y1, y2 = AF.normalize_pair(ac, bc, mode)
+    # (x - mu) keeps the input's absolute rounding: atol scales with |x| / std
+    tol = 2e-6 * (1.0 + abs(offset) * 4)
+    assert_close(y1, r1, tol * 4, 1e-5, 'y1')
+    assert_close(y2, r2, tol * 4, 1e-5, 'y2')
+    da, db = torch.autograd.grad([y1, y2], [ac, bc], [cu(g1), cu(g2)])
+    gt = max(float(ra.abs().max()), float(rb.abs().max()))
+    assert_close(da, ra, 2e-5 * gt * (1.0 + abs(offset)), 1e-4, 'gx1')
+    assert_close(db, rb, 2e-5 * gt * (1.0 + abs(offset)), 1e-4, 'gx2')
+    # one-sided gradient request
+    ac2 = cu(x1).requires_grad_(True)
+    y1b, y2b = AF.normalize_pair(ac2, cu(x2), mode)
+    da2, = torch.autograd.grad([y1b, y2b], [ac2], [cu(g1), cu(g2)])
+    assert_close(da2, ra, 2e-5 * gt * (1.0 + abs(offset)), 1e-4, 'gx1 only')
+
+
 def test_correlation_module_signature(AF):
     from arflow_amd.correlation import Correlation, compute_cost_volume
     m = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
@@ -134,6 +176,34 @@ def test_correlation_module_signature(AF):
 def _warp_tol(x, H, W):
     ulp = 2.0 ** -23 * max(H, W)
     return (2e-6 + 4 * ulp) * float(x.abs().max())
+
+
+@pytest.mark.parametrize('pad', ['zeros', 'border'])
+def test_warp_backward_adversarial_fields(oracle, pad):
+    """d/d src and d/d flow of the warp on fields that stress the scatter -> per-cell-list conversion:
+    smooth, violently noisy (windows beyond the LDS budget: direct-atomic fallback), all pixels converging
+    onto a few source cells (1000-entry lists), everything leaving the image (empty tiles)."""
+    from arflow_amd.warp_utils import flow_warp
+    gen = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 5, 21, 70
+    src = torch.randn(B, C, H, W, generator=gen)
+    go = torch.randn(B, C, H, W, generator=gen)
+    ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
+    fields = {
+        'smooth': torch.nn.functional.interpolate(3 * torch.randn(B, 2, 3, 5, generator=gen), (H, W), mode='bilinear',
+                                                  align_corners=True),
+        'noise': 9 * torch.randn(B, 2, H, W, generator=gen),
+        'huge noise': 60 * torch.randn(B, 2, H, W, generator=gen),
+        'converging': (torch.stack([W / 2 - xs, H / 2 - ys]) * 0.96).expand(B, 2, H, W).clone(),
+        'leaving': torch.full((B, 2, H, W), 500.0),
+    }
+    for name, flow in fields.items():
+        s_ref, f_ref = src.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+        r_s, r_f = torch.autograd.grad(oracle.flow_warp(s_ref, f_ref, pad=pad, align_corners=True), [s_ref, f_ref], go)
+        sc, fc = cu(src).requires_grad_(True), cu(flow).requires_grad_(True)
+        gs, gf = torch.autograd.grad(flow_warp(sc, fc, pad=pad, align_corners=True), [sc, fc], cu(go))
+        assert_close(gs, r_s, 1e-5 * max(1.0, float(r_s.abs().max())), 1e-4, '%s %s gsrc' % (name, pad))
+        assert_close(gf, r_f, 1e-5 * max(1.0, float(r_f.abs().max())), 1e-4, '%s %s gflow' % (name, pad))
 
 
 def test_flow_warp_golden(golden):

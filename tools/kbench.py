@@ -79,13 +79,19 @@ def main():
         planes = lib.arflow_corr_sign_planes(C, w, 4)
         sign = torch.zeros(B2, planes, h, w, device=dev, dtype=torch.int32) if planes else None
         if want('corr_fwd') or want('corr_bwd'):
-            rec('arflow_corr_fwd', (B2, C, h, w, 4), timeit(lambda: lib.arflow_corr_fwd(p(x1), p(x2), p(out), p(sign), B2, C, h, w, 4, 0.1, s), args.iters))
+            rec('arflow_corr_fwd', (B2, C, h, w, 4, planes), timeit(lambda: lib.arflow_corr_fwd(p(x1), p(x2), p(out), p(sign), B2, C, h, w, 4, 0.1, s), args.iters))
         if want('corr_bwd'):
-            rec('arflow_corr_bwd', (B2, C, h, w, 4, True), timeit(lambda: lib.arflow_corr_bwd(p(go), None if planes else p(out), p(sign), p(x1), p(x2), p(g1), p(g2), B2, C, h, w, 4, 0.1, s), args.iters))
+            rec('arflow_corr_bwd', (B2, C, h, w, 4, planes or 81), timeit(lambda: lib.arflow_corr_bwd(p(go), None if planes else p(out), p(sign), p(x1), p(x2), p(g1), p(g2), B2, C, h, w, 4, 0.1, s), args.iters))
         if want('warp_fwd'):
             rec('arflow_warp_fwd', (B2, C, h, w), timeit(lambda: lib.arflow_warp_fwd(p(x2), p(fl), p(wout), None, B2, C, h, w, h, w, 2 * h * w, 0, 1, 0, s), args.iters))
         if want('warp_bwd'):
             rec('arflow_warp_bwd', (B2, C, h, w, True), timeit(lambda: lib.arflow_warp_bwd(p(x1), p(x2), p(fl), p(g2), p(gfl), B2, C, h, w, h, w, 2 * h * w, 0, 1, 0, s), args.iters))
+        if want('featnorm'):
+            n = C * h * w
+            acc = torch.empty(4 * B2, device=dev, dtype=torch.float64)
+            stt = torch.empty(B2, 4, device=dev)
+            rec('arflow_featnorm_fwd', (B2, n), timeit(lambda: lib.arflow_featnorm_fwd(p(x1), p(x2), p(g1), p(g2), p(acc), p(stt), B2, n, 0, s), args.iters))
+            rec('arflow_featnorm_bwd', (B2, n), timeit(lambda: lib.arflow_featnorm_bwd(p(x1), p(x2), p(x1), p(x2), p(stt), p(acc), p(g1), p(g2), B2, n, 0, s), args.iters))
     # loss side: B = batch/2 image pairs at full resolution, per direction
     B = max(1, B2 // 2)
     im1 = torch.rand(B, 3, H0, W0, device=dev, generator=g)
