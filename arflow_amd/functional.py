@@ -154,6 +154,7 @@ def correlation(x1, x2, max_displacement=4, negative_slope=1.0):
 
 # ------------------------------------------------------------------------------------------------
 FEATNORM = {'joint': 0, 'avg': 1}
+FEATNORM_SLOTS = 8  # ARFLOW_FEATNORM_SLOTS
 
 
 class FeatureNormFunction(torch.autograd.Function):
@@ -170,7 +171,7 @@ class FeatureNormFunction(torch.autograd.Function):
         B = x1.shape[0]
         n = x1[0].numel()
         y1, y2 = torch.empty_like(x1), torch.empty_like(x2)
-        acc = torch.empty(4 * B, device=x1.device, dtype=torch.float64)
+        acc = torch.empty(4 * FEATNORM_SLOTS * B, device=x1.device, dtype=torch.float64)
         stats = torch.empty(B, 4, device=x1.device, dtype=torch.float32)
         with torch.cuda.device_of(x1):
             _call('arflow_featnorm_fwd', _p(x1), _p(x2), _p(y1), _p(y2), _p(acc), _p(stats), B, n, mode, _stream(),
@@ -187,7 +188,7 @@ class FeatureNormFunction(torch.autograd.Function):
         g1, g2 = g1.contiguous(), g2.contiguous()
         d1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
         d2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
-        acc = torch.empty(4 * B, device=x1.device, dtype=torch.float64)
+        acc = torch.empty(4 * FEATNORM_SLOTS * B, device=x1.device, dtype=torch.float64)
         with torch.cuda.device_of(x1):
             _call('arflow_featnorm_bwd', _p(g1), _p(g2), _p(x1), _p(x2), _p(stats), _p(acc), _p(d1), _p(d2), B, n,
                   ctx.mode, _stream(), key=(B, n))
