@@ -69,6 +69,36 @@ __device__ __forceinline__ TapPlan plan_taps(const Taps& t, int Hs, int Ws) {
 namespace fwd_win {
 constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24, CCH = 4;
 
+// Stage CCH channels of the source window (bh rows x WQ aligned float4 each) into LDS.  All loads of a
+// thread are issued before the first LDS write and none is branched around (a slot outside the window
+// reads the plane's first 16 bytes instead): with `if (inside) win[..] = load` per slot hipcc waits for
+// every load before issuing the next -- 2 x CCH serialised round trips per chunk.
+template <int WQ>
+__device__ __forceinline__ void stage_window(float* __restrict__ win, const float* __restrict__ sp, int c0, int C,
+                                             int ss, int Ws, int ax0, int by0, int bh) {
+  constexpr int WP = 4 * WQ, ITER = (HMAX * WQ + NT - 1) / NT;
+  const int per = bh * WQ;
+  float4 v[CCH][ITER];
+  bool ok[ITER];
+  int dst[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int i = threadIdx.x + it * NT;
+    const int r = i / WQ, xs = i - r * WQ;
+    ok[it] = i < per && ax0 + 4 * xs < Ws;
+    dst[it] = r * WP + 4 * xs;
+    const long off = ok[it] ? (long)(by0 + r) * Ws + ax0 + 4 * xs : 0;
+#pragma unroll
+    for (int c = 0; c < CCH; ++c)
+      v[c][it] = *reinterpret_cast<const float4*>(sp + (long)min(c0 + c, C - 1) * ss + off);
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it)
+#pragma unroll
+    for (int c = 0; c < CCH; ++c)
+      if (ok[it] && c0 + c < C) *reinterpret_cast<float4*>(win + c * HMAX * WP + dst[it]) = v[c][it];
+}
+
 template <int WQ>  // window row = WQ float4
 __device__ __forceinline__ void run(float* __restrict__ win, const float* __restrict__ sp, float* __restrict__ op,
                                     const TapPlan& p, bool inside, int C, int ss, int os, int Ws, int ax0, int by0,
@@ -76,20 +106,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
   constexpr int WP = 4 * WQ;
   // channels are independent: at small levels they are spread over gridDim.y workgroups per tile
   for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
-    // stage CCH channels of the window: bh rows x WQ aligned float4 each
-    const int per = bh * WQ;
-#pragma unroll
-    for (int c = 0; c < CCH; ++c) {
-      if (c0 + c < C) {
-        const float* s = sp + (long)(c0 + c) * ss + (long)by0 * Ws + ax0;
-        for (int i = threadIdx.x; i < per; i += NT) {
-          const int r = i / WQ, xs = i - r * WQ;
-          if (ax0 + 4 * xs < Ws)
-            *reinterpret_cast<float4*>(win + (c * HMAX + r) * WP + 4 * xs) =
-                *reinterpret_cast<const float4*>(s + (long)r * Ws + 4 * xs);
-        }
-      }
-    }
+    stage_window<WQ>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
     __syncthreads();
     if (inside) {
 #pragma unroll
@@ -265,22 +282,10 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
                                     float& gix, float& giy) {
   constexpr int WP = 4 * WQ;
   for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
-    const int per = bh * WQ;
     float g[CCH];
 #pragma unroll
     for (int c = 0; c < CCH; ++c) g[c] = (inside && c0 + c < C) ? gop[(long)(c0 + c) * os] : 0.f;
-#pragma unroll
-    for (int c = 0; c < CCH; ++c) {
-      if (c0 + c < C) {
-        const float* s = sp + (long)(c0 + c) * ss + (long)by0 * Ws + ax0;
-        for (int i = threadIdx.x; i < per; i += 256) {
-          const int r = i / WQ, xs = i - r * WQ;
-          if (ax0 + 4 * xs < Ws)
-            *reinterpret_cast<float4*>(win + (c * HMAX + r) * WP + 4 * xs) =
-                *reinterpret_cast<const float4*>(s + (long)r * Ws + 4 * xs);
-        }
-      }
-    }
+    fwd_win::stage_window<WQ>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CCH; ++c) {
