@@ -125,21 +125,42 @@ def pmc_traffic(name, shape):
     def grid(tiles, threads):
         return 8 * cdiv(tiles, 8) * threads
 
+    def split(tiles, chunks, cap):  # channel chunks spread over gridDim.y (mirrors the launch code)
+        n = 1
+        while n * 2 <= chunks and tiles * n * 2 <= cap:
+            n *= 2
+        return n
+
+    def per_sample(B, n, floats_per_block):  # featnorm.hip blocks_per_sample()
+        return max(1, min(cdiv(n, floats_per_block), cdiv(2048, B)))
+
     keys = []
     if name in ('arflow_census_fwd', 'arflow_census_bwd'):
         B, H, W = shape
         keys = ['census4::%s_kernel<3>|%d' % (name[-3:], grid(cdiv(W, 64) * cdiv(H, 16) * B, 256))]
-    elif name in ('arflow_corr_fwd', 'arflow_corr_bwd'):
+    elif name == 'arflow_corr_fwd':
         B, C, H, W = shape[:4]
-        tiles = cdiv(W, 32) * cdiv(H, 8) * B * (2 if name.endswith('bwd') else 1)
-        keys = ['corr_v2::%s_kernel<%d>|%d' % (name[-3:], 2 if tiles >= 768 else 4, grid(tiles, 192))]
+        tiles = cdiv(W, 32) * cdiv(H, 8) * B
+        keys = ['corr_v2::fwd_kernel<%d>|%d' % (2 if tiles >= 768 else 4, grid(tiles, 192))]
+    elif name == 'arflow_corr_bwd':
+        B, C, H, W = shape[:4]
+        act = {0: 0, 3: 2}.get(int(shape[5]) if len(shape) > 5 else 0, 1)
+        tiles = cdiv(W, 32) * cdiv(H, 8) * B * 2
+        keys = ['corr_v2::bwd_kernel<%d, %d>|%d' % (2 if tiles >= 768 else 4, act,
+                                                   grid(tiles, 192) * split(tiles, C // 4, 1024))]
     elif name == 'arflow_warp_fwd':
         B, C, H, W = shape
-        keys = ['warp_fwd_kernel|%d' % grid(cdiv(W, 32) * cdiv(H, 8) * B, 256)]
+        tiles = cdiv(W, 32) * cdiv(H, 8) * B
+        keys = ['warp_fwd_kernel|%d' % (grid(tiles, 256) * split(tiles, C // 4, 2048))]
     elif name == 'arflow_warp_bwd':
         B, C, H, W, with_src = shape
-        g = grid(cdiv(W, 32) * cdiv(H, 8) * B, 256)
+        tiles = cdiv(W, 32) * cdiv(H, 8) * B
+        g = grid(tiles, 256) * split(tiles, C // 4, 2048)
         keys = ['warp_bwd_flow_kernel|%d' % g] + (['lds_scatter::warp_bwd_src_kernel|%d' % g] if with_src else [])
+    elif name in ('arflow_featnorm_fwd', 'arflow_featnorm_bwd'):
+        B, n = shape
+        k1, k2 = ('moment_kernel', 'apply_kernel') if name.endswith('fwd') else ('bwd_sum_kernel', 'bwd_apply_kernel')
+        keys = ['%s|%d' % (k1, per_sample(B, n, 256 * 16) * B * 256), '%s|%d' % (k2, per_sample(B, n, 256 * 4) * B * 256)]
     if not keys or any(k not in table for k in keys):
         return None
     return sum(table[k]['hbm_bytes'] for k in keys)
