@@ -30,21 +30,38 @@ __device__ __forceinline__ float dpen(float v, int penalty) {
   return v / sqrtf(fmaf(v, v, 1e-6f));
 }
 
+// Sum over channels of |I(p) - I(q)| with the element offsets p, q inside one plane.  CI > 0: the channel
+// count is a compile-time constant (3 for every caller) and all 2*CI loads are issued before the first
+// use; CI == 0 keeps the runtime loop.  (With the runtime loop hipcc waits for each pair of loads: a
+// dozen serialised round trips per pixel made the full-resolution launches latency-bound.)
+template <int CI>
+__device__ __forceinline__ float chan_absdiff(const SmoothArgs& a, const float* ib, long p, long q) {
+  const long cs = (long)a.H * a.W;
+  float s = 0.f;
+  if (CI > 0) {
+    float u[CI > 0 ? CI : 1], v[CI > 0 ? CI : 1];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) u[c] = ib[c * cs + p], v[c] = ib[c * cs + q];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) s += fabsf(u[c] - v[c]);
+  } else {
+    for (int c = 0; c < a.Ci; ++c) s += fabsf(ib[c * cs + p] - ib[c * cs + q]);
+  }
+  return s;
+}
 // edge weight for the x-difference anchored at (y,x); caller guarantees validity.
+template <int CI>
 __device__ __forceinline__ float edge_wx(const SmoothArgs& a, const float* ib, int y, int x) {
   const int xa = a.order == 1 ? x + 1 : x + 2;
   const int xb = a.order == 1 ? x : (a.wmode == 0 ? x + 1 : x);
-  const long cs = (long)a.H * a.W;
-  float s = 0.f;
-  for (int c = 0; c < a.Ci; ++c) s += fabsf(ib[c * cs + (long)y * a.W + xa] - ib[c * cs + (long)y * a.W + xb]);
+  const float s = chan_absdiff<CI>(a, ib, (long)y * a.W + xa, (long)y * a.W + xb);
   return __expf(-(s / (float)a.Ci) * a.alpha);
 }
+template <int CI>
 __device__ __forceinline__ float edge_wy(const SmoothArgs& a, const float* ib, int y, int x) {
   const int ya = a.order == 1 ? y + 1 : y + 2;
   const int yb = a.order == 1 ? y : (a.wmode == 0 ? y + 1 : y);
-  const long cs = (long)a.H * a.W;
-  float s = 0.f;
-  for (int c = 0; c < a.Ci; ++c) s += fabsf(ib[c * cs + (long)ya * a.W + x] - ib[c * cs + (long)yb * a.W + x]);
+  const float s = chan_absdiff<CI>(a, ib, (long)ya * a.W + x, (long)yb * a.W + x);
   return __expf(-(s / (float)a.Ci) * a.alpha);
 }
 // flow differences anchored at (y,x)
@@ -58,22 +75,30 @@ __device__ __forceinline__ float diff_y(const SmoothArgs& a, const float* f, int
   return a.order == 1 ? (r[W] - r[0]) * a.fscale : ((r[2 * W] - r[W]) - (r[W] - r[0])) * a.fscale;
 }
 
-__global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __restrict__ sums) {
+// A workgroup covers 256 columns x `rows` rows (chosen at launch so that ~2000 workgroups remain): fewer
+// partial sums meet in the slotted rows (9216 workgroups x 2 atomics over 64 rows serialised ~290 deep at
+// 384 x 640).
+template <int CI>
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __restrict__ sums, int rows) {
   __shared__ float red[2 * 4];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
   const int o = a.order;
   float part[2] = {0.f, 0.f};
   if (x < a.W) {
     const float* ib = a.img + (long)b * a.Ci * a.H * a.W;
     const float* fb = a.flow + (long)b * a.fbs;
     const long cs = (long)a.H * a.W;
-    if (x < a.W - o) {
-      const float w = edge_wx(a, ib, y, x);
-      part[0] = w * (pen(diff_x(a, fb, y, x), a.penalty) + pen(diff_x(a, fb + cs, y, x), a.penalty));
-    }
-    if (y < a.H - o) {
-      const float w = edge_wy(a, ib, y, x);
-      part[1] = w * (pen(diff_y(a, fb, y, x), a.penalty) + pen(diff_y(a, fb + cs, y, x), a.penalty));
+    for (int r = 0; r < rows; ++r) {
+      const int y = blockIdx.y * rows + r;
+      if (y >= a.H) break;
+      if (x < a.W - o) {
+        const float w = edge_wx<CI>(a, ib, y, x);
+        part[0] += w * (pen(diff_x(a, fb, y, x), a.penalty) + pen(diff_x(a, fb + cs, y, x), a.penalty));
+      }
+      if (y < a.H - o) {
+        const float w = edge_wy<CI>(a, ib, y, x);
+        part[1] += w * (pen(diff_y(a, fb, y, x), a.penalty) + pen(diff_y(a, fb + cs, y, x), a.penalty));
+      }
     }
   }
   af_block_sum<2>(part, red);
@@ -84,6 +109,7 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __
   }
 }
 
+template <int CI>
 __global__ __launch_bounds__(256) void smooth_bwd_kernel(SmoothArgs a, const float* __restrict__ coef,
                                                         float* __restrict__ gflow) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
@@ -102,13 +128,13 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(SmoothArgs a, const flo
     const float s = o == 1 ? st1[k] : st2[k];
     const int xa = x - k;
     if (xa >= 0 && xa < a.W - o) {
-      const float w = edge_wx(a, ib, y, xa) * s * cx;
+      const float w = edge_wx<CI>(a, ib, y, xa) * s * cx;
       g[0] = fmaf(w, dpen(diff_x(a, fb, y, xa), a.penalty), g[0]);
       g[1] = fmaf(w, dpen(diff_x(a, fb + cs, y, xa), a.penalty), g[1]);
     }
     const int ya = y - k;
     if (ya >= 0 && ya < a.H - o) {
-      const float w = edge_wy(a, ib, ya, x) * s * cy;
+      const float w = edge_wy<CI>(a, ib, ya, x) * s * cy;
       g[0] = fmaf(w, dpen(diff_y(a, fb, ya, x), a.penalty), g[0]);
       g[1] = fmaf(w, dpen(diff_y(a, fb + cs, ya, x), a.penalty), g[1]);
     }
@@ -175,7 +201,13 @@ extern "C" int arflow_smooth_fwd(const float* flow, const float* img, float* sum
   hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
   if (e != hipSuccess) return af_hip_status(e);
   SmoothArgs a{flow, img, Ci, H, W, flow_bstride, flow_scale, alpha, order, wmode, penalty};
-  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, st, a, sums);
+  long rows = (long)af_cdiv(W, 256) * H * B / 2048;
+  rows = rows < 1 ? 1 : (rows > 8 ? 8 : rows);
+  const dim3 grid(af_cdiv(W, 256), af_cdiv(H, rows), B);
+  if (Ci == 3)
+    hipLaunchKernelGGL(smooth_fwd_kernel<3>, grid, dim3(256), 0, st, a, sums, (int)rows);
+  else
+    hipLaunchKernelGGL(smooth_fwd_kernel<0>, grid, dim3(256), 0, st, a, sums, (int)rows);
   return af_launch_status();
 }
 
@@ -187,8 +219,10 @@ extern "C" int arflow_smooth_bwd(const float* flow, const float* img, const floa
   AF_REQUIRE_PTR(coef);
   AF_REQUIRE_PTR(gflow);
   SmoothArgs a{flow, img, Ci, H, W, flow_bstride, flow_scale, alpha, order, wmode, penalty};
-  hipLaunchKernelGGL(smooth_bwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, a,
-                     coef, gflow);
+  if (Ci == 3)
+    hipLaunchKernelGGL(smooth_bwd_kernel<3>, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, a, coef, gflow);
+  else
+    hipLaunchKernelGGL(smooth_bwd_kernel<0>, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, a, coef, gflow);
   return af_launch_status();
 }
 

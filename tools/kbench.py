@@ -121,6 +121,13 @@ def main():
         rec('arflow_photo_bwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_photo_bwd(p(im1), p(im2), p(mask), None, p(coef), p(rec3), B, 3, H0, W0, s), args.iters))
     if want('splat'):
         rec('arflow_splat_map', (B, H0 // 4, W0 // 4), timeit(lambda: lib.arflow_splat_map(p(fl2), p(dham), B, H0 // 4, W0 // 4, 2 * (H0 // 4) * (W0 // 4), 0, s), args.iters))
+    if args.levels == 'pwclite':  # unFlowLoss works at full resolution
+        if want('smooth_fwd'):
+            rec('arflow_smooth_fwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_smooth_fwd(p(fl0), p(im1), p(sums), B, 3, H0, W0, 2 * H0 * W0, 1.0 / 384, 10.0, 1, 0, 0, s), args.iters))
+        if want('smooth_bwd'):
+            rec('arflow_smooth_bwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_smooth_bwd(p(fl0), p(im1), p(coef), p(gfl0), B, 3, H0, W0, 2 * H0 * W0, 1.0 / 384, 10.0, 1, 0, 0, s), args.iters))
+        if want('splat_map'):
+            rec('arflow_splat_map', (B, H0, W0), timeit(lambda: lib.arflow_splat_map(p(fl0), p(dham), B, H0, W0, 2 * H0 * W0, 1, s), args.iters))
     if want('smooth_fwd'):
         rec('arflow_smooth_fwd', (B, 3, H0 // 4, W0 // 4), timeit(lambda: lib.arflow_smooth_fwd(p(fl2), p(sm), p(sums), B, 3, H0 // 4, W0 // 4, 2 * (H0 // 4) * (W0 // 4), 1.0, 150.0, 1, 1, 1, s), args.iters))
     if want('smooth_bwd'):
