@@ -38,7 +38,7 @@ PROTOTYPES = {
     'arflow_up4_clamp_mul': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

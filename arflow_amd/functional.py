@@ -63,7 +63,7 @@ def stop_kernel_timing():
     return out
 
 
-NSLOT, SLOT_STRIDE = 64, 32  # ARFLOW_NSLOT / ARFLOW_SLOT_STRIDE of include/arflow_hip.h
+NSLOT, SLOT_STRIDE = 256, 32  # ARFLOW_NSLOT / ARFLOW_SLOT_STRIDE of include/arflow_hip.h
 
 
 def _new_sums(device):

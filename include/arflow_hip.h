@@ -56,7 +56,7 @@ typedef void* arflow_stream_t; /* hipStream_t */
  * workgroup adds its partial into one of ARFLOW_NSLOT rows, each on its own 128-byte line.
  * A `sums` argument points to ARFLOW_NSLOT*ARFLOW_SLOT_STRIDE floats (zero-filled by the callee);
  * quantity k is  sum_{s<NSLOT} sums[s*ARFLOW_SLOT_STRIDE + k]. */
-#define ARFLOW_NSLOT 64
+#define ARFLOW_NSLOT 256
 #define ARFLOW_SLOT_STRIDE 32
 
 int arflow_abi_version(void);
