@@ -23,6 +23,8 @@ PROTOTYPES = {
     'arflow_corr_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_featnorm_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
     'arflow_featnorm_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
+    'arflow_bias_act_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_l, c_f, c_fp],
+    'arflow_bias_act_bwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_l, c_f, c_fp],
     'arflow_warp_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_warp_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_splat_map': [c_fp, c_fp, c_i, c_i, c_i, c_l, c_i, c_fp],
@@ -38,7 +40,7 @@ PROTOTYPES = {
     'arflow_up4_clamp_mul': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -1,6 +1,6 @@
 #include "common.hpp"
 
-extern "C" int arflow_abi_version(void) { return 5; }
+extern "C" int arflow_abi_version(void) { return 6; }
 
 extern "C" const char* arflow_strerror(int code) {
   switch (code) {

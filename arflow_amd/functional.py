@@ -200,6 +200,47 @@ def normalize_pair(x1, x2, mode='joint'):
 
 
 # ------------------------------------------------------------------------------------------------
+class BiasLeakyReLUFunction(torch.autograd.Function):
+    """y = leaky_relu(x + bias[None, :, None, None], slope), IN PLACE on x (the bias-free output of a
+    convolution, which autograd does not need again); backward = LeakyReLU derivative and bias gradient in
+    one pass.  Replaces the bias add + nn.LeakyReLU(0.1, inplace=True) behind every conv of the reference
+    models (models/pwclite.py:10-23)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope):
+        _need_gpu(x)
+        if not x.is_contiguous():
+            raise ValueError('bias_leaky_relu expects a contiguous [B,C,...] tensor')
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        if bias is not None:
+            _need_gpu(bias)
+            bias = bias.contiguous()
+        with torch.cuda.device_of(x):
+            _call('arflow_bias_act_fwd', _p(x), _p(bias), _p(x), B, C, hw, float(slope), _stream(), key=(B, C, hw))
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.slope, ctx.has_bias = float(slope), bias is not None
+        return x
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, = ctx.saved_tensors
+        B, C = y.shape[0], y.shape[1]
+        hw = y[0, 0].numel()
+        gout = gout.contiguous()
+        gin = torch.empty_like(gout)
+        gb = torch.empty(C, device=y.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        with torch.cuda.device_of(y):
+            _call('arflow_bias_act_bwd', _p(gout), _p(y), _p(gin), _p(gb), B, C, hw, ctx.slope, _stream(), key=(B, C, hw))
+        return gin, gb, None
+
+
+def bias_leaky_relu(x, bias, slope=0.1):
+    return BiasLeakyReLUFunction.apply(x, bias, slope)
+
+
+# ------------------------------------------------------------------------------------------------
 class WarpFunction(torch.autograd.Function):
     """out = bilinear(src, grid + flow); with ``want_valid`` also the in-image mask of the sampling
     positions (mask_invalid(flow_to_warp(flow)), utils/uflow_utils.py:35-50) from the same launch."""

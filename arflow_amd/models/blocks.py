@@ -2,6 +2,23 @@
 Module / parameter names follow the reference so its checkpoints load by name."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as AF
+
+bias_act = AF.bias_leaky_relu  # (conv output, bias, slope) -> activation; substituted by oracle.host_models on CPU
+
+
+class ConvAct(nn.Sequential):
+    """Sequential(Conv2d(bias=True), LeakyReLU) with the reference's parameter names (``0.weight``,
+    ``0.bias``), evaluated as bias-free MIOpen convolution + ONE fused bias/LeakyReLU pass (and one fused
+    LeakyReLU-derivative/bias-gradient pass backward) instead of conv, bias add, LeakyReLU and a separate
+    full-tensor reduction for the bias gradient."""
+
+    def forward(self, x):
+        c, act = self[0], self[1]
+        y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        return bias_act(y, c.bias, act.negative_slope)
 
 
 def conv(in_planes, out_planes, kernel_size=3, stride=1, dilation=1, isReLU=True):
@@ -10,6 +27,7 @@ def conv(in_planes, out_planes, kernel_size=3, stride=1, dilation=1, isReLU=True
                         padding=((kernel_size - 1) * dilation) // 2, bias=True)]
     if isReLU:
         layers.append(nn.LeakyReLU(0.1, inplace=True))
+        return ConvAct(*layers)
     return nn.Sequential(*layers)
 
 

@@ -106,6 +106,16 @@ int arflow_featnorm_bwd(const float* g1, const float* g2, const float* x1, const
                         const float* stats, double* acc, float* gx1, float* gx2, int B, long n, int mode,
                         arflow_stream_t stream);
 
+/* ---- conv epilogue of the host models ------------------------------------------------------------
+ * y = lrelu(x + bias[c]) for x, y: [B, C, HW] (x == y allowed; bias nullable): the bias add and
+ * LeakyReLU(0.1) that follow every convolution of the reference models (models/pwclite.py:10-23,
+ * models/uflow_model.py:271-287) in one pass.  Backward: gin = gout * (y > 0 ? 1 : negative_slope) and
+ * gbias[c] = sum_{b,hw} gin (gbias nullable, zero-filled here; fp32 atomics). */
+int arflow_bias_act_fwd(const float* x, const float* bias, float* y, int B, int C, long HW,
+                        float negative_slope, arflow_stream_t stream);
+int arflow_bias_act_bwd(const float* gout, const float* y, float* gin, float* gbias, int B, int C, long HW,
+                        float negative_slope, arflow_stream_t stream);
+
 /* ---- bilinear warp ----------------------------------------------------------------------------
  * out[b,c,y,x] = bilinear(src[b,c], x + flow[b,0,y,x], y + flow[b,1,y,x]) with torch grid_sample
  * semantics (pad zeros|border, align_corners) after the reference's normalise/un-normalise round

@@ -162,6 +162,24 @@ def test_feature_normalisation_vs_oracle(AF, oracle, mode, shape, offset):
     assert_close(da2, ra, 2e-5 * gt * (1.0 + abs(offset)), 1e-4, 'gx1 only')
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 24, 40), (3, 5, 3, 5), (1, 128, 6, 10), (2, 3, 96, 160)])
+def test_bias_leaky_relu(AF, shape):
+    """Fused conv epilogue: leaky_relu(x + bias) in place, gradient w.r.t. x and the bias."""
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(*shape, generator=gen)
+    bias = torch.randn(shape[1], generator=gen)
+    go = torch.randn(*shape, generator=gen)
+    a, bb = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(a + bb.view(1, -1, 1, 1), 0.1)
+    ra, rb = torch.autograd.grad(ref, [a, bb], go)
+    xc, bc = cu(x).requires_grad_(True), cu(bias).requires_grad_(True)
+    y = AF.bias_leaky_relu(xc * 1.0, bc, 0.1)  # * 1.0: the op works in place on a non-leaf
+    assert_close(y, ref, 1e-6, 1e-6, 'fwd')
+    ga, gb = torch.autograd.grad(y, [xc, bc], cu(go))
+    assert_close(ga, ra, 1e-6, 1e-6, 'gx')
+    assert_close(gb, rb, 1e-5 * max(1.0, float(rb.abs().max())), 1e-5, 'gbias')
+
+
 def test_correlation_module_signature(AF):
     from arflow_amd.correlation import Correlation, compute_cost_volume
     m = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
