@@ -7,7 +7,8 @@ import torch.nn.functional as func
 from .. import functional as AF
 from .. import uflow_utils
 from ..correlation import compute_cost_volume
-from .blocks import init_conv_weights, pair_batches
+from . import blocks
+from .blocks import ConvAct, init_conv_weights, pair_batches
 
 
 def normalize_features(feature_list, normalize, center, moments_across_channels, moments_across_images):
@@ -50,8 +51,11 @@ class PWCFeaturePyramid(nn.Module):
         features = []
         for group in self._convs:
             for conv in group:
-                x = func.pad(x, pad=[1, 1, 1, 1], mode='constant', value=0)
-                x = func.leaky_relu(conv(x), negative_slope=self._leaky_relu_alpha)
+                # the reference zero-pads by 1 explicitly and convolves 'valid' (models/uflow_model.py:453-457):
+                # the same numbers as padding=1 inside the convolution, without the padded copy;
+                # bias-free conv + fused bias / LeakyReLU pass
+                x = blocks.bias_act(func.conv2d(x, conv.weight, None, conv.stride, 1, conv.dilation),
+                                    conv.bias, self._leaky_relu_alpha)
             features.append(x)
         return features
 
@@ -82,8 +86,8 @@ class PWCFlow(nn.Module):
             layers = nn.ModuleList()
             c_in = 81 + 32 + (0 if i == self._num_levels - 1 else 2 + self._num_context_up_channels)
             for c in (128, 128, 96, 64, 32):
-                layers.append(nn.Sequential(nn.Conv2d(c_in, c, kernel_size=(3, 3), stride=1, padding='same'),
-                                            nn.LeakyReLU(negative_slope=self._leaky_relu_alpha)))
+                layers.append(ConvAct(nn.Conv2d(c_in, c, kernel_size=(3, 3), stride=1, padding='same'),
+                                      nn.LeakyReLU(negative_slope=self._leaky_relu_alpha)))
                 c_in += c
             layers.append(nn.Conv2d(32, 2, kernel_size=(3, 3), padding='same'))
             result.append(layers)
@@ -145,8 +149,17 @@ class PWCFlow(nn.Module):
             context_up = self._context_up_layers[level](context)
             flows.insert(0, flow)
         refinement = torch.cat([context, flow], dim=1)
-        for layer in self._refine_model:
-            refinement = layer(refinement)
+        mods = list(self._refine_model)
+        i = 0
+        while i < len(mods):  # Conv2d followed by LeakyReLU -> bias-free conv + fused bias / LeakyReLU pass
+            m = mods[i]
+            if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                refinement = blocks.bias_act(func.conv2d(refinement, m.weight, None, m.stride, m.padding, m.dilation),
+                                             m.bias, mods[i + 1].negative_slope)
+                i += 2
+            else:
+                refinement = m(refinement)
+                i += 1
         if drops is not None:
             refinement = refinement * drops[k]
         flows[0] = flow + refinement
