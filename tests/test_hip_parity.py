@@ -493,3 +493,81 @@ def test_mv_loss_vs_oracle():
     gg = torch.autograd.grad(got[0], c12 + c10)
     for a, b in zip(gg, rg):
         assert_close(a, b, 2e-7 + 2e-4 * float(b.abs().max()), 2e-3, 'mv dflow')
+
+
+def test_random_shapes_fuzz(AF, oracle):
+    """Seeded sweep over ragged shapes (odd sizes, one-row / one-column maps, sizes around the 8 x 32 and
+    16 x 64 tile edges, widths with and without 16-byte alignment): forward and gradients of the main ops
+    against the oracle, with the tolerances of the dedicated tests."""
+    import random
+    from arflow_amd.warp_utils import flow_warp
+    from arflow_amd.uflow_utils import census_loss, compute_range_map
+    from arflow_amd.loss_blocks import smooth_grad_1st
+    rnd = random.Random(1234)
+    gen = torch.Generator().manual_seed(99)
+    sizes = [(1, 1), (1, 9), (9, 1), (2, 3), (7, 31), (8, 32), (9, 33), (16, 64), (17, 65), (23, 40), (5, 100)]
+    for trial in range(14):
+        H, W = sizes[trial % len(sizes)] if trial < len(sizes) else (rnd.randint(1, 40), rnd.randint(1, 90))
+        B, C = rnd.randint(1, 3), rnd.choice([1, 3, 4, 8, 12, 32])
+        d = 4 if H > 4 else max(1, H - 1)
+        x1, x2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+        tag = 'trial %d B%d C%d %dx%d' % (trial, B, C, H, W)
+        # correlation (+ fused LeakyReLU) with gradients
+        n = (2 * d + 1) ** 2
+        go = torch.randn(B, n, H, W, generator=gen)
+        a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        ref = torch.nn.functional.leaky_relu(oracle.correlation(a, b, d), 0.1)
+        r1, r2 = torch.autograd.grad(ref, [a, b], go)
+        ac, bc = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
+        y = AF.correlation(ac, bc, d, negative_slope=0.1)
+        assert_close(y, ref, 1e-6, 1e-5, tag + ' corr')
+        g1, g2 = torch.autograd.grad(y, [ac, bc], cu(go))
+        assert_close(g1, r1, 1e-5, 1e-4, tag + ' corr gx1')
+        assert_close(g2, r2, 1e-5, 1e-4, tag + ' corr gx2')
+        # warp with both gradients (a 1-pixel-wide map divides by W - 1 = 0 in the reference's norm_grid,
+        # utils/warp_utils.py:16-23: NaN there, skipped here)
+        flow = 2.5 * torch.randn(B, 2, H, W, generator=gen)
+        gw = torch.randn(B, C, H, W, generator=gen)
+        pad, ac_ = rnd.choice(['zeros', 'border']), rnd.choice([True, False])
+        if min(H, W) == 1:
+            continue
+        s_ref, f_ref = x2.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+        wr = oracle.flow_warp(s_ref, f_ref, pad=pad, align_corners=ac_)
+        rs, rf = torch.autograd.grad(wr, [s_ref, f_ref], gw)
+        sc, fc = cu(x2).requires_grad_(True), cu(flow).requires_grad_(True)
+        wy = flow_warp(sc, fc, pad=pad, align_corners=ac_)
+        tol = (2e-6 + 4 * 2.0 ** -23 * max(H, W)) * max(1.0, float(x2.abs().max()))
+        assert_close(wy, wr, tol, 1e-5, tag + ' warp')
+        gs, gf = torch.autograd.grad(wy, [sc, fc], cu(gw))
+        assert_close(gs, rs, 1e-5 * max(1.0, float(rs.abs().max())), 1e-4, tag + ' warp gsrc')
+        assert_close(gf, rf, 2e-4 * max(1.0, float(rf.abs().max())), 1e-3, tag + ' warp gflow')
+        # splat map, feature normalisation
+        assert_close(compute_range_map(cu(flow)), oracle.compute_range_map(flow), 1e-5, 1e-4, tag + ' range map')
+        if C * H * W >= 2:
+            ya, yb = AF.normalize_pair(cu(x1), cu(x2), 'joint')
+            ra, rb = oracle.normalize_features_joint([x1, x2])
+            assert_close(ya, ra, 1e-5, 1e-5, tag + ' norm')
+            assert_close(yb, rb, 1e-5, 1e-5, tag + ' norm')
+        # census loss and smoothness on 3-channel images (the reference's zero_mask_border,
+        # utils/uflow_utils.py:234-238, breaks on maps smaller than its 3-pixel border: H, W >= 7 only)
+        im1, im2 = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, 3, H, W, generator=gen)
+        mask = (torch.rand(B, 1, H, W, generator=gen) > 0.2).float()
+        if H >= 7 and W >= 7:
+            i2 = im2.clone().requires_grad_(True)
+            lr = oracle.census_loss(im1, i2, mask)
+            i2c = cu(im2).requires_grad_(True)
+            lc = census_loss(cu(im1), i2c, cu(mask))
+            assert abs(float(lc) - float(lr)) <= 5e-5 * abs(float(lr)) + 1e-6, (tag, float(lc), float(lr))
+            if float(mask[:, :, 3:-3, 3:-3].sum()) > 0:
+                gr, = torch.autograd.grad(lr, i2)
+                gc, = torch.autograd.grad(lc, i2c)
+                assert_close(gc, gr, 2e-5 * max(1e-3, float(gr.abs().max())), 2e-4, tag + ' census grad')
+        if H >= 2 and W >= 2:
+            fl = flow.clone().requires_grad_(True)
+            sr = oracle.smooth_grad_1st(fl, im1, 10.0)
+            flc = cu(flow).requires_grad_(True)
+            sc_ = smooth_grad_1st(flc, cu(im1), 10.0)
+            assert abs(float(sc_) - float(sr)) <= 2e-5 * abs(float(sr)) + 1e-7, (tag, float(sc_), float(sr))
+            gsr, = torch.autograd.grad(sr, fl)
+            gsc, = torch.autograd.grad(sc_, flc)
+            assert_close(gsc, gsr, 1e-6 + 1e-5 * float(gsr.abs().max()), 1e-4, tag + ' smooth grad')
