@@ -105,13 +105,21 @@ __device__ __forceinline__ bool tile_of_block(int ntx, int nty, int nimg, int& t
 inline unsigned grid_for_tiles(int T) { return 8u * (unsigned)((T + 7) / 8); }
 
 // ------------------------------------------------------------------------------------------------
-template <int NBUF>
-__global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
-                                                    float* __restrict__ out, unsigned* __restrict__ sign_bits,
-                                                    int nimg, int C, int H, int W, float inv_c, float slope) {
-  constexpr int BUF = SRC_FLOATS + X1_FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + TH * SP];  // + pad: prefetch runs a channel ahead
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave id in an SGPR
+// G > 1 (coarse levels with many channels, e.g. PWCLite's 6x10 level with C = 192: 16 tiles x 48 serial
+// chunks left the chip idle for 66 us): the workgroup has G groups of 3 waves; group g runs the channel
+// chunks g, g+G, ... through its own DMA ring, and the groups' accumulators meet through LDS at the end
+// (float atomics into the volume were 6x slower than no split at all).  Needs (C / 4) % G == 0; one such
+// workgroup (G = 4: 12 waves, 124 KB of LDS) fills a CU.
+template <int NBUF, int G>
+__global__ __launch_bounds__(NT * G, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                        float* __restrict__ out, unsigned* __restrict__ sign_bits,
+                                                        int nimg, int C, int H, int W, float inv_c, float slope) {
+  constexpr int BUF = SRC_FLOATS + X1_FLOATS, RING = NBUF * BUF;
+  static_assert(G == 1 || G * RING >= NW * 3 * N * 64 * PX, "the accumulator exchange reuses the rings");
+  __shared__ __attribute__((aligned(16))) float lds_all[G * RING + TH * SP];  // + pad: prefetch runs a channel ahead
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave id in an SGPR
+  const int grp = wave_all / NW, wave = wave_all - grp * NW;
+  float* lds = lds_all + grp * RING;
   int xg, y;
   lane_xy(lane, xg, y);
   int btx, bty, b;
@@ -135,12 +143,12 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
 #pragma unroll
     for (int m = 0; m < NK; ++m) {
       const int k = wave + NW * m;
-      const float* g = (k < SRC_DMA ? x2b : x1b) + (long)chunk * CC * cs;
+      const float* g = (k < SRC_DMA ? x2b : x1b) + (long)(grp + chunk * G) * CC * cs;
       dma16(off[m] >= 0 ? g + off[m] : g_zero16, buf + k * 256);  // x1 region follows x2: block k carries over
     }
   };
 
-  const int nchunk = C / CC;
+  const int nchunk = C / CC / G;  // per group
 #pragma unroll
   for (int pre = 0; pre < NBUF - 1; ++pre)
     if (pre < nchunk) issue(pre);
@@ -192,6 +200,34 @@ __global__ __launch_bounds__(NT, 3) void fwd_kernel(const float* __restrict__ x1
     }
   }
 
+  if (G > 1) {  // groups 1 .. G-1 hand their partial sums to group 0, one group at a time through the rings
+    f32x4* xch = reinterpret_cast<f32x4*>(lds_all) + (wave * 3 * N) * 64 + lane;
+#pragma unroll 1
+    for (int g = 1; g < G; ++g) {
+      __syncthreads();  // all FMAs done with the rings / group 0 has consumed the previous hand-over
+      if (grp == g) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            f32x4 t;
+            t.x = acc[k][j][0], t.y = acc[k][j][1], t.z = acc[k][j][2], t.w = acc[k][j][3];
+            xch[(k * N + j) * 64] = t;
+          }
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const f32x4 t = xch[(k * N + j) * 64];
+            acc[k][j][0] += t.x, acc[k][j][1] += t.y, acc[k][j][2] += t.z, acc[k][j][3] += t.w;
+          }
+      }
+    }
+    if (grp != 0) return;
+  }
   const int gy = ty0 + y, gx = tx0 + 4 * xg;
   if (gy >= H || gx >= W) return;
   float* ob = out + (((long)b * N * N + 3 * wave * N) * H + gy) * W + gx;
@@ -433,10 +469,13 @@ inline int launch_fwd(const float* x1, const float* x2, float* out, unsigned* si
   dim3 grid(grid_for_tiles(tiles));
   // many tiles: 4 workgroups per CU hide each other's DMA latency, keep LDS small (2 buffers);
   // few tiles: one workgroup per CU -> deeper ring so its own DMA runs 3 chunks ahead
-  if (tiles >= 768)
-    hipLaunchKernelGGL(fwd_kernel<2>, grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, 1.0f / (float)C, slope);
+  const float inv_c = 1.0f / (float)C;
+  if (tiles <= 160 && (C / CC) % 4 == 0 && C / CC >= 8)  // few tiles, >= 2 chunks per group: 4 channel groups per workgroup
+    hipLaunchKernelGGL((fwd_kernel<2, 4>), grid, dim3(NT * 4), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
+  else if (tiles >= 768)
+    hipLaunchKernelGGL((fwd_kernel<2, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
   else
-    hipLaunchKernelGGL(fwd_kernel<4>, grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, 1.0f / (float)C, slope);
+    hipLaunchKernelGGL((fwd_kernel<4, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
   return af_launch_status();
 }
 

@@ -148,7 +148,10 @@ def pmc_traffic(name, shape):
     elif name == 'arflow_corr_fwd':
         B, C, H, W = shape[:4]
         tiles = cdiv(W, 32) * cdiv(H, 8) * B
-        keys = ['corr_v2::fwd_kernel<%d>|%d' % (2 if tiles >= 768 else 4, grid(tiles, 192))]
+        if tiles <= 160 and (C // 4) % 4 == 0 and C // 4 >= 8:
+            keys = ['corr_v2::fwd_kernel<2, 4>|%d' % grid(tiles, 768)]
+        else:
+            keys = ['corr_v2::fwd_kernel<%d, 1>|%d' % (2 if tiles >= 768 else 4, grid(tiles, 192))]
     elif name == 'arflow_corr_bwd':
         B, C, H, W = shape[:4]
         act = {0: 0, 3: 2}.get(int(shape[5]) if len(shape) > 5 else 0, 1)
