@@ -67,13 +67,15 @@ __device__ __forceinline__ TapPlan plan_taps(const Taps& t, int Hs, int Ws) {
 // and ran at 25 % of the HBM roofline) and the four taps of every pixel are then read from LDS.
 // Falls back to direct (batched) gathers when the window does not fit or rows are not 16-byte aligned.
 namespace fwd_win {
-constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24, CCH = 4;
+constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24;
+// CCH = channels staged per chunk: 4 for feature maps; 3 for the 3-channel image warps of the losses, whose
+// smaller window (20.7 instead of 27.6 KB) lets 7 instead of 5 workgroups share a CU
 
 // Stage CCH channels of the source window (bh rows x WQ aligned float4 each) into LDS.  All loads of a
 // thread are issued before the first LDS write and none is branched around (a slot outside the window
 // reads the plane's first 16 bytes instead): with `if (inside) win[..] = load` per slot hipcc waits for
 // every load before issuing the next -- 2 x CCH serialised round trips per chunk.
-template <int WQ>
+template <int WQ, int CCH>
 __device__ __forceinline__ void stage_window(float* __restrict__ win, const float* __restrict__ sp, int c0, int C,
                                              int ss, int Ws, int ax0, int by0, int bh) {
   constexpr int WP = 4 * WQ, ITER = (HMAX * WQ + NT - 1) / NT;
@@ -99,14 +101,14 @@ __device__ __forceinline__ void stage_window(float* __restrict__ win, const floa
       if (ok[it] && c0 + c < C) *reinterpret_cast<float4*>(win + c * HMAX * WP + dst[it]) = v[c][it];
 }
 
-template <int WQ>  // window row = WQ float4
+template <int WQ, int CCH>  // window row = WQ float4
 __device__ __forceinline__ void run(float* __restrict__ win, const float* __restrict__ sp, float* __restrict__ op,
                                     const TapPlan& p, bool inside, int C, int ss, int os, int Ws, int ax0, int by0,
                                     int bh, int l0, int l1, int l2, int l3) {
   constexpr int WP = 4 * WQ;
   // channels are independent: at small levels they are spread over gridDim.y workgroups per tile
   for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
-    stage_window<WQ>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
+    stage_window<WQ, CCH>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
     __syncthreads();
     if (inside) {
 #pragma unroll
@@ -126,6 +128,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
 }
 }  // namespace fwd_win
 
+template <int CCH>
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ src,
                                                        const float* __restrict__ flow,
                                                        float* __restrict__ out, float* __restrict__ valid,
@@ -194,10 +197,10 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
     const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
     if (aw <= 48)
-      run<12>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 48 + cxa, cya * 48 + cxb, cyb * 48 + cxa,
+      run<12, CCH>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 48 + cxa, cya * 48 + cxb, cyb * 48 + cxa,
               cyb * 48 + cxb);
     else
-      run<18>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 72 + cxa, cya * 72 + cxb, cyb * 72 + cxa,
+      run<18, CCH>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 72 + cxa, cya * 72 + cxb, cyb * 72 + cxa,
               cyb * 72 + cxb);
     return;
   }
@@ -207,8 +210,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     return;
   }
   // fallback: direct gathers, U channels per round (all 4*U loads in flight together)
-  constexpr int U = 4;
-  static_assert(U == CCH, "channel split assumes U == CCH");
+  constexpr int U = CCH;  // (the channel split over gridDim.y counts chunks of CCH)
   for (int c0 = blockIdx.y * U; c0 < C; c0 += gridDim.y * U) {
     float a[U][4];
 #pragma unroll
@@ -273,9 +275,8 @@ __device__ __forceinline__ Taps no_taps() {
 // backward of the loss-side image warps (their source is detached, losses/uflow_loss.py:31,34).
 // ------------------------------------------------------------------------------------------------
 namespace flow_grad {
-using fwd_win::CCH;
 using fwd_win::HMAX;
-template <int WQ>
+template <int WQ, int CCH>
 __device__ __forceinline__ void run(float* __restrict__ win, const float* __restrict__ sp,
                                     const float* __restrict__ gop, const TapPlan& p, const Taps& t, bool inside, int C,
                                     int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
@@ -285,7 +286,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
     float g[CCH];
 #pragma unroll
     for (int c = 0; c < CCH; ++c) g[c] = (inside && c0 + c < C) ? gop[(long)(c0 + c) * os] : 0.f;
-    fwd_win::stage_window<WQ>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
+    fwd_win::stage_window<WQ, CCH>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CCH; ++c) {
@@ -300,6 +301,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
 }
 }  // namespace flow_grad
 
+template <int CCH>
 __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restrict__ gout,
                                                             const float* __restrict__ src,
                                                             const float* __restrict__ flow, float* __restrict__ gflow,
@@ -332,10 +334,10 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
     const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
     const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
     if (aw <= 48)
-      flow_grad::run<12>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa, cya * 48 + cxb,
+      flow_grad::run<12, CCH>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa, cya * 48 + cxb,
                          cyb * 48 + cxa, cyb * 48 + cxb, gix, giy);
     else
-      flow_grad::run<18>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa, cya * 72 + cxb,
+      flow_grad::run<18, CCH>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa, cya * 72 + cxb,
                          cyb * 72 + cxa, cyb * 72 + cxb, gix, giy);
   } else if (inside && !empty) {
     for (int c = blockIdx.y; c < C; c += gridDim.y) {  // direct gathers (window too large or unaligned rows)
@@ -502,19 +504,12 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
       entry[slot] = make_float2(__int_as_float((int)threadIdx.x), wgt[k]);
     }
   __syncthreads();
-#if defined(AF_ABLATE) && AF_ABLATE == 1
-  return;
-#endif
   // 4. per channel chunk: stage gout pixel-major (one ds_write_b128 per pixel, one ds_read_b128 per list
   //    entry brings its 4 channels), gather per non-empty cell, one global atomic per cell and channel
   int buf = 0;
   auto fetch = [&](int c0, float (&v)[CCH]) {
 #pragma unroll
-#if defined(AF_ABLATE) && AF_ABLATE == 5
-    for (int c = 0; c < CCH; ++c) v[c] = (float)(c0 + c);
-#else
     for (int c = 0; c < CCH; ++c) v[c] = (c0 + c < C && inside) ? gop[(c0 + c) * os] : 0.f;
-#endif
   };
   float nv[CCH];  // the next chunk's gradients travel while the current chunk is gathered
   fetch(blockIdx.y * CCH, nv);
@@ -531,11 +526,7 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
       // four list entries per trip (most cells have <= 4 contributors): the entry reads go out together,
       // then the four gradient reads -- two dependent LDS round trips per cell instead of two per entry.
       // Slots past the end re-read the last entry with weight 0 (same sum, same order).
-#if defined(AF_ABLATE) && AF_ABLATE == 4
-      for (int e = beg; e < beg; e += 4) {
-#else
       for (int e = beg; e < end; e += 4) {
-#endif
         float2 en[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -556,13 +547,7 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
       float* d = gp + (long)c0 * ss + (long)(by0 + (ci >> 7)) * Ws + bx0 + (ci & 127);
 #pragma unroll
       for (int c = 0; c < CCH; ++c)
-#if defined(AF_ABLATE) && (AF_ABLATE == 2 || AF_ABLATE == 5)
-        if (c0 + c < C && acc[c] == 12345.678f) d[c * ss] = acc[c];
-#elif defined(AF_ABLATE) && AF_ABLATE == 3
-        if (c0 + c < C) d[c * ss] = acc[c];
-#else
         if (c0 + c < C) atomicAdd(d + c * ss, acc[c]);
-#endif
     }
     // gt is double-buffered: the next chunk stages into the other buffer; its barrier orders this chunk's
     // reads before this buffer is overwritten two chunks later
@@ -749,9 +734,13 @@ extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, 
   AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
   AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
   const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
-  hipLaunchKernelGGL(warp_fwd_kernel, dim3(af_grid_for_tiles(tiles), channel_split(tiles, C)), dim3(256), 0,
-                     (hipStream_t)stream, src, flow, out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode,
-                     align_corners, norm_mode);
+  if (C <= 3)  // image warps of the losses: 3 channels per chunk (smaller LDS window, more workgroups per CU)
+    hipLaunchKernelGGL(warp_fwd_kernel<3>, dim3(af_grid_for_tiles(tiles), 1), dim3(256), 0, (hipStream_t)stream, src, flow,
+                       out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  else
+    hipLaunchKernelGGL(warp_fwd_kernel<4>, dim3(af_grid_for_tiles(tiles), channel_split(tiles, C)), dim3(256), 0,
+                       (hipStream_t)stream, src, flow, out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode,
+                       align_corners, norm_mode);
   return af_launch_status();
 }
 
@@ -782,8 +771,12 @@ extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float*
       hipError_t e = hipMemsetAsync(gflow, 0, sizeof(float) * (size_t)B * 2 * H * W, st);
       if (e != hipSuccess) return af_hip_status(e);
     }
-    hipLaunchKernelGGL(warp_bwd_flow_kernel, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
-                       gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+    if (C <= 3)
+      hipLaunchKernelGGL(warp_bwd_flow_kernel<3>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
+                         gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+    else
+      hipLaunchKernelGGL(warp_bwd_flow_kernel<4>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
+                         gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
   }
   return af_launch_status();
 }

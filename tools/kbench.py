@@ -36,7 +36,7 @@ def timeit(fn, iters):
 
 
 def main():
-    if os.environ.get('ARFLOW_LIB_PATH'):  # ablation builds (tools only)
+    if os.environ.get('ARFLOW_LIB_PATH'):  # an alternative build of the library (A/B timing; tools only)
         _lib.LIB_PATH = os.environ['ARFLOW_LIB_PATH']
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=50)
