@@ -68,8 +68,10 @@ __device__ __forceinline__ TapPlan plan_taps(const Taps& t, int Hs, int Ws) {
 // Falls back to direct (batched) gathers when the window does not fit or rows are not 16-byte aligned.
 namespace fwd_win {
 constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24;
-// CCH = channels staged per chunk: 4 for feature maps; 3 for the 3-channel image warps of the losses, whose
-// smaller window (20.7 instead of 27.6 KB) lets 7 instead of 5 workgroups share a CU
+// CCH = channels staged per chunk.  These kernels are latency-bound chains (flow -> taps -> box -> window -> taps),
+// so what counts is how many workgroups a CU holds, i.e. the LDS window: 4 channels (27.6 KB, 5 per CU) ran the
+// B16 C32 96x160 forward in 24.5 us, 2 channels (13.8 KB, 8 per CU = the wave limit) in 18.8 us; the 3-channel
+// image warps of the losses use 3 (20.7 KB, 7 per CU): 30.0 -> 24.7 us
 
 // Stage CCH channels of the source window (bh rows x WQ aligned float4 each) into LDS.  All loads of a
 // thread are issued before the first LDS write and none is branched around (a slot outside the window
@@ -738,7 +740,7 @@ extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, 
     hipLaunchKernelGGL(warp_fwd_kernel<3>, dim3(af_grid_for_tiles(tiles), 1), dim3(256), 0, (hipStream_t)stream, src, flow,
                        out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
   else
-    hipLaunchKernelGGL(warp_fwd_kernel<4>, dim3(af_grid_for_tiles(tiles), channel_split(tiles, C)), dim3(256), 0,
+    hipLaunchKernelGGL(warp_fwd_kernel<2>, dim3(af_grid_for_tiles(tiles), channel_split(tiles, C)), dim3(256), 0,
                        (hipStream_t)stream, src, flow, out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode,
                        align_corners, norm_mode);
   return af_launch_status();
@@ -775,7 +777,7 @@ extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float*
       hipLaunchKernelGGL(warp_bwd_flow_kernel<3>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
                          gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
     else
-      hipLaunchKernelGGL(warp_bwd_flow_kernel<4>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
+      hipLaunchKernelGGL(warp_bwd_flow_kernel<2>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
                          gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
   }
   return af_launch_status();

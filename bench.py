@@ -161,12 +161,12 @@ def pmc_traffic(name, shape):
     elif name == 'arflow_warp_fwd':
         B, C, H, W = shape
         tiles = cdiv(W, 32) * cdiv(H, 8) * B
-        keys = ['warp_fwd_kernel<%d>|%d' % (3 if C <= 3 else 4, grid(tiles, 256) * split(tiles, C // 4, 2048))]
+        keys = ['warp_fwd_kernel<%d>|%d' % (3 if C <= 3 else 2, grid(tiles, 256) * split(tiles, C // 4, 2048))]
     elif name == 'arflow_warp_bwd':
         B, C, H, W, with_src = shape
         tiles = cdiv(W, 32) * cdiv(H, 8) * B
         g = grid(tiles, 256) * split(tiles, C // 4, 2048)
-        keys = ['warp_bwd_flow_kernel<%d>|%d' % (3 if C <= 3 else 4, g)] + (['lds_scatter::warp_bwd_src_kernel|%d' % g] if with_src else [])
+        keys = ['warp_bwd_flow_kernel<%d>|%d' % (3 if C <= 3 else 2, g)] + (['lds_scatter::warp_bwd_src_kernel|%d' % g] if with_src else [])
     elif name in ('arflow_featnorm_fwd', 'arflow_featnorm_bwd'):
         B, n = shape
         k1, k2 = ('moment_kernel', 'apply_kernel') if name.endswith('fwd') else ('bwd_sum_kernel', 'bwd_apply_kernel')
