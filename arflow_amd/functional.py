@@ -45,11 +45,21 @@ def _flow_view(flow):
 _timing = None  # list of (name, key, start_event, end_event) while kernel timing is on
 
 
+_paused = False
+
+
 def start_kernel_timing():
     """Bracket every C-ABI launch with HIP events recorded on the launch stream (torch's current
     stream).  Used by bench.py for the per-kernel roofline; off by default."""
     global _timing
     _timing = []
+
+
+def pause_kernel_timing(paused):
+    """Keep the records but stop / resume bracketing launches (bench.py samples a subset of its steps: two
+    event records per launch cost ~10 us of host time each, which a launch-bound step feels)."""
+    global _paused
+    _paused = bool(paused)
 
 
 def stop_kernel_timing():
@@ -77,7 +87,7 @@ def _fold_sums(buf, k):
 
 def _call(name, *args, key=None):
     lib = _lib.load()
-    if _timing is not None and key is not None:
+    if _timing is not None and key is not None and not _paused:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, name)(*args)

@@ -14,6 +14,7 @@ For N > 1 launch with:  python -m torch.distributed.run --nnodes=1 --nproc-per-n
                         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -278,11 +279,22 @@ def main():
     sync()
     if not args.no_kernel_timing:
         AF.start_kernel_timing()
+    # HIP events bracket the launches of every 4th timed step (sampling keeps the host-side cost of the
+    # event records out of a launch-bound step; the averages are still taken live inside the timed region)
+    sampled = [i for i in range(args.steps) if i % 4 == 0]
+    # CPython's cyclic collector stops the launching thread for ~75 ms roughly once per 50 steps (the step
+    # creates ~10^5 short-lived objects; nothing in it needs cycle collection): collect now, keep it off for
+    # the timed steps -- what a training loop would do between epochs
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if not args.no_kernel_timing:
+            AF.pause_kernel_timing(i % 4 != 0)
         step(img)
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timing = AF.stop_kernel_timing() if not args.no_kernel_timing else {}
     finite = bool(torch.isfinite(step.last).item())
 
@@ -310,11 +322,11 @@ def main():
         for (name, shape), durs in timing.items():
             (glue if name in HOST_GLUE else per)[(name, shape)] = (sum(durs), len(durs))
         if glue:
-            g_ms = sum(v[0] for v in glue.values()) / args.steps
-            g_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in glue.items()) / args.steps
+            g_ms = sum(v[0] for v in glue.values()) / len(sampled)
+            g_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in glue.items()) / len(sampled)
             line['host_glue'] = {'what': 'fused bias+LeakyReLU conv epilogue of the host model (arflow_bias_act_*)',
                                  'ms_per_step': g_ms, 'algorithmic_GB_per_step': g_bytes / 1e9,
-                                 'GBps': g_bytes / (g_ms * 1e-3) / 1e9, 'launches_per_step': sum(v[1] for v in glue.values()) / args.steps}
+                                 'GBps': g_bytes / (g_ms * 1e-3) / 1e9, 'launches_per_step': sum(v[1] for v in glue.values()) / len(sampled)}
         if per:
             (name, shape), (tot, n) = max(per.items(), key=lambda kv: kv[1][0])
             avg_ms = tot / n
@@ -322,15 +334,15 @@ def main():
             ach = nbytes / (avg_ms * 1e-3) / 1e9
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(name, shape), 'kernel': name, 'shape': list(shape),
-                                'avg_us': 1e3 * avg_ms, 'launches_per_step': n / args.steps,
+                                'avg_us': 1e3 * avg_ms, 'launches_per_step': n / len(sampled),
                                 'algorithmic_bytes': nbytes}
-            hot_ms = sum(v[0] for v in per.values()) / args.steps
-            hot_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in per.items()) / args.steps
+            hot_ms = sum(v[0] for v in per.values()) / len(sampled)
+            hot_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in per.items()) / len(sampled)
             line['hot_path'] = {'ms_per_step': hot_ms, 'algorithmic_GB_per_step': hot_bytes / 1e9,
                                 'GBps': hot_bytes / (hot_ms * 1e-3) / 1e9,
                                 'frac_of_hbm_peak': hot_bytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 'share_of_step': hot_ms / (1e3 * elapsed / args.steps),
-                                'kernels': {('%s%s' % (k[0], list(k[1]))): {'us': 1e3 * v[0] / v[1], 'n': v[1] / args.steps,
+                                'kernels': {('%s%s' % (k[0], list(k[1]))): {'us': 1e3 * v[0] / v[1], 'n': v[1] / len(sampled),
                                                                            'GBps': algorithmic_bytes(k[0], k[1]) / (v[0] / v[1] * 1e-3) / 1e9}
                                             for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:12]}}
         if world == 1 and not args.no_cpu_baseline:
