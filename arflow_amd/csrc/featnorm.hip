@@ -22,7 +22,7 @@ constexpr int NT = 256, VPT = 16;  // floats per thread per tensor and trip (4 f
 constexpr int NSLOT = ARFLOW_FEATNORM_SLOTS;
 
 // sum over the block of NV doubles per thread; result in thread 0
-template <int NV>
+template <int NV, int NTH = NT>
 __device__ __forceinline__ void block_sum_f64(double (&v)[NV], double* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -32,14 +32,14 @@ __device__ __forceinline__ void block_sum_f64(double (&v)[NV], double* scratch) 
   }
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) scratch[k * (NT / 64) + wave] = v[k];
+    for (int k = 0; k < NV; ++k) scratch[k * (NTH / 64) + wave] = v[k];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       double s = 0.0;
-      for (int w = 0; w < NT / 64; ++w) s += scratch[k * (NT / 64) + w];
+      for (int w = 0; w < NTH / 64; ++w) s += scratch[k * (NTH / 64) + w];
       v[k] = s;
     }
   }
@@ -50,12 +50,16 @@ struct Moments {
 };
 
 // (sum x1, sum x1^2, sum x2, sum x2^2) -> the sample's statistics
+__device__ __forceinline__ Moments moments_from_totals(const double (&a)[4], long n, int mode);
 __device__ __forceinline__ Moments moments_of(const double* rows, long n, int mode) {
   double a[4] = {0.0, 0.0, 0.0, 0.0};
   for (int r = 0; r < NSLOT; ++r) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[k] += rows[4 * r + k];
   }
+  return moments_from_totals(a, n, mode);
+}
+__device__ __forceinline__ Moments moments_from_totals(const double (&a)[4], long n, int mode) {
   const double dn = (double)n;
   const double m1 = a[0] / dn, m2 = a[2] / dn;
   double mu, var;
@@ -216,6 +220,126 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
   }
 }
 
+// Coarsest pyramid levels (n <= SMALL_N floats per tensor and sample; at n = 30720 the two-launch form is
+// already faster, 9.7 vs 12.9 us): ONE launch, one 1024-thread workgroup
+// per sample does the reduction and the apply pass back to back (the second read comes from L2) -- the
+// two-launch form spends more time in launch latency and the accumulator zero-fill than in the kernels.
+constexpr int NTS = 1024;
+constexpr long SMALL_N = 16384;
+
+__global__ __launch_bounds__(NTS) void fwd_small_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                        float* __restrict__ y1, float* __restrict__ y2,
+                                                        float* __restrict__ stats, long n, int mode) {
+  __shared__ double scratch[4 * (NTS / 64)];
+  __shared__ double tot[4];
+  const int b = blockIdx.x;
+  const float* p1 = x1 + (long)b * n;
+  const float* p2 = x2 + (long)b * n;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  const long n4 = (n % 4 == 0) ? n / 4 : 0;
+  for (long i0 = 0; i0 < n4; i0 += 4 * NTS) {  // fp32 partials over <= 16 values, double beyond
+    float a1 = 0.f, q1 = 0.f, a2 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long i = i0 + (long)k * NTS + threadIdx.x;
+      if (i < n4) {
+        const float4 u = reinterpret_cast<const float4*>(p1)[i];
+        const float4 v = reinterpret_cast<const float4*>(p2)[i];
+        a1 += (u.x + u.y) + (u.z + u.w);
+        q1 = fmaf(u.x, u.x, fmaf(u.y, u.y, fmaf(u.z, u.z, fmaf(u.w, u.w, q1))));
+        a2 += (v.x + v.y) + (v.z + v.w);
+        q2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, q2))));
+      }
+    }
+    s[0] += (double)a1, s[1] += (double)q1, s[2] += (double)a2, s[3] += (double)q2;
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += NTS) {
+    const float u = p1[i], v = p2[i];
+    s[0] += (double)u, s[1] += (double)u * (double)u, s[2] += (double)v, s[3] += (double)v * (double)v;
+  }
+  block_sum_f64<4, NTS>(s, scratch);
+  if (threadIdx.x == 0) tot[0] = s[0], tot[1] = s[1], tot[2] = s[2], tot[3] = s[3];
+  __syncthreads();
+  const double a[4] = {tot[0], tot[1], tot[2], tot[3]};
+  const Moments m = moments_from_totals(a, n, mode);
+  const float sd = sqrtf(m.var + 1e-16f);
+  if (threadIdx.x == 0) {
+    float* st = stats + 4 * b;
+    st[0] = m.m1, st[1] = m.m2, st[2] = m.mu, st[3] = sd;
+  }
+  float* o1 = y1 + (long)b * n;
+  float* o2 = y2 + (long)b * n;
+  for (long i = threadIdx.x; i < n4; i += NTS) {
+    const float4 u = reinterpret_cast<const float4*>(p1)[i];
+    const float4 v = reinterpret_cast<const float4*>(p2)[i];
+    reinterpret_cast<float4*>(o1)[i] =
+        make_float4((u.x - m.mu) / sd, (u.y - m.mu) / sd, (u.z - m.mu) / sd, (u.w - m.mu) / sd);
+    reinterpret_cast<float4*>(o2)[i] =
+        make_float4((v.x - m.mu) / sd, (v.y - m.mu) / sd, (v.z - m.mu) / sd, (v.w - m.mu) / sd);
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += NTS) {
+    o1[i] = (p1[i] - m.mu) / sd;
+    o2[i] = (p2[i] - m.mu) / sd;
+  }
+}
+
+__global__ __launch_bounds__(NTS) void bwd_small_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                        const float* __restrict__ x1, const float* __restrict__ x2,
+                                                        const float* __restrict__ stats, float* __restrict__ d1,
+                                                        float* __restrict__ d2, long n, int mode) {
+  __shared__ double scratch[2 * (NTS / 64)];
+  __shared__ double tot[2];
+  const int b = blockIdx.x;
+  const float* st = stats + 4 * b;
+  const float mu = st[2];
+  const long o = (long)b * n;
+  double s[2] = {0.0, 0.0};
+  const long n4 = (n % 4 == 0) ? n / 4 : 0;
+  for (long i0 = 0; i0 < n4; i0 += 4 * NTS) {
+    float sg = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long i = i0 + (long)k * NTS + threadIdx.x;
+      if (i < n4) {
+        const float4 ga = reinterpret_cast<const float4*>(g1 + o)[i], xa = reinterpret_cast<const float4*>(x1 + o)[i];
+        const float4 gb = reinterpret_cast<const float4*>(g2 + o)[i], xb = reinterpret_cast<const float4*>(x2 + o)[i];
+        sg += ((ga.x + ga.y) + (ga.z + ga.w)) + ((gb.x + gb.y) + (gb.z + gb.w));
+        sq = fmaf(ga.x, xa.x - mu, fmaf(ga.y, xa.y - mu, fmaf(ga.z, xa.z - mu, fmaf(ga.w, xa.w - mu, sq))));
+        sq = fmaf(gb.x, xb.x - mu, fmaf(gb.y, xb.y - mu, fmaf(gb.z, xb.z - mu, fmaf(gb.w, xb.w - mu, sq))));
+      }
+    }
+    s[0] += (double)sg, s[1] += (double)sq;
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += NTS) {
+    const float ga = g1[o + i], gb = g2[o + i];
+    s[0] += (double)ga + (double)gb;
+    s[1] += (double)ga * (double)(x1[o + i] - mu) + (double)gb * (double)(x2[o + i] - mu);
+  }
+  block_sum_f64<2, NTS>(s, scratch);
+  if (threadIdx.x == 0) tot[0] = s[0], tot[1] = s[1];
+  __syncthreads();
+  const double r = 1.0 / (double)st[3], G = tot[0], Q = tot[1], dn = (double)n;
+  const float rf = (float)r;
+  const float cg = (float)(r * G / (2.0 * dn));
+  const float cq = (float)(mode == ARFLOW_FEATNORM_JOINT ? r * r * r * Q / (2.0 * dn - 1.0) : r * r * r * Q / (2.0 * (dn - 1.0)));
+  const float c1 = mode == ARFLOW_FEATNORM_JOINT ? st[2] : st[0], c2 = mode == ARFLOW_FEATNORM_JOINT ? st[2] : st[1];
+  auto f = [&](float g, float x, float c) { return fmaf(rf, g, -cg) - cq * (x - c); };
+  for (long i = threadIdx.x; i < n4; i += NTS) {
+    if (d1) {
+      const float4 g = reinterpret_cast<const float4*>(g1 + o)[i], x = reinterpret_cast<const float4*>(x1 + o)[i];
+      reinterpret_cast<float4*>(d1 + o)[i] = make_float4(f(g.x, x.x, c1), f(g.y, x.y, c1), f(g.z, x.z, c1), f(g.w, x.w, c1));
+    }
+    if (d2) {
+      const float4 g = reinterpret_cast<const float4*>(g2 + o)[i], x = reinterpret_cast<const float4*>(x2 + o)[i];
+      reinterpret_cast<float4*>(d2 + o)[i] = make_float4(f(g.x, x.x, c2), f(g.y, x.y, c2), f(g.z, x.z, c2), f(g.w, x.w, c2));
+    }
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += NTS) {
+    if (d1) d1[o + i] = f(g1[o + i], x1[o + i], c1);
+    if (d2) d2[o + i] = f(g2[o + i], x2[o + i], c2);
+  }
+}
+
 // enough workgroups to fill the chip (~2048) without slicing a sample finer than one trip per block
 inline unsigned blocks_per_sample(int B, long n, int floats_per_block) {
   long nb = (n + floats_per_block - 1) / floats_per_block;
@@ -237,6 +361,10 @@ extern "C" int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, 
   AF_REQUIRE(B > 0 && B <= 65535 && n >= 2, ARFLOW_ESHAPE);
   AF_REQUIRE(mode == ARFLOW_FEATNORM_JOINT || mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
+  if (n <= SMALL_N) {
+    hipLaunchKernelGGL(fwd_small_kernel, dim3(B), dim3(NTS), 0, st, x1, x2, y1, y2, stats, n, mode);
+    return af_launch_status();
+  }
   hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 4 * NSLOT * (size_t)B, st);
   if (e != hipSuccess) return af_hip_status(e);
   hipLaunchKernelGGL(moment_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, x1, x2, acc, n);
@@ -258,6 +386,10 @@ extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float
   AF_REQUIRE(mode == ARFLOW_FEATNORM_JOINT || mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
   if (!gx1 && !gx2) return ARFLOW_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (n <= SMALL_N) {
+    hipLaunchKernelGGL(bwd_small_kernel, dim3(B), dim3(NTS), 0, st, g1, g2, x1, x2, stats, gx1, gx2, n, mode);
+    return af_launch_status();
+  }
   hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 4 * NSLOT * (size_t)B, st);
   if (e != hipSuccess) return af_hip_status(e);
   hipLaunchKernelGGL(bwd_sum_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
