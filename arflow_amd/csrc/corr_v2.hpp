@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT * G, 3) void fwd_kernel(const float* __restrict_
                                                         float* __restrict__ out, unsigned* __restrict__ sign_bits,
                                                         int nimg, int C, int H, int W, float inv_c, float slope) {
   constexpr int BUF = SRC_FLOATS + X1_FLOATS, RING = NBUF * BUF;
-  static_assert(G == 1 || G * RING >= NW * 3 * N * 64 * PX, "the accumulator exchange reuses the rings");
+  static_assert(G == 1 || G * RING >= NW * N * 64 * PX, "the accumulator exchange reuses the rings");
   __shared__ __attribute__((aligned(16))) float lds_all[G * RING + TH * SP];  // + pad: prefetch runs a channel ahead
   const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave id in an SGPR
   const int grp = wave_all / NW, wave = wave_all - grp * NW;
@@ -200,30 +200,29 @@ __global__ __launch_bounds__(NT * G, 3) void fwd_kernel(const float* __restrict_
     }
   }
 
-  if (G > 1) {  // groups 1 .. G-1 hand their partial sums to group 0, one group at a time through the rings
-    f32x4* xch = reinterpret_cast<f32x4*>(lds_all) + (wave * 3 * N) * 64 + lane;
+  if (G > 1) {  // groups 1 .. G-1 hand their partial sums to group 0 through the rings, one row shift at a time
+    f32x4* xch = reinterpret_cast<f32x4*>(lds_all) + (wave * N) * 64 + lane;
 #pragma unroll 1
     for (int g = 1; g < G; ++g) {
-      __syncthreads();  // all FMAs done with the rings / group 0 has consumed the previous hand-over
-      if (grp == g) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 3; ++k) {
+        __syncthreads();  // all FMAs done with the rings / group 0 has consumed the previous hand-over
+        if (grp == g) {
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             f32x4 t;
             t.x = acc[k][j][0], t.y = acc[k][j][1], t.z = acc[k][j][2], t.w = acc[k][j][3];
-            xch[(k * N + j) * 64] = t;
+            xch[j * 64] = t;
           }
-      }
-      __syncthreads();
-      if (grp == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
+        }
+        __syncthreads();
+        if (grp == 0) {
 #pragma unroll
           for (int j = 0; j < N; ++j) {
-            const f32x4 t = xch[(k * N + j) * 64];
+            const f32x4 t = xch[j * 64];
             acc[k][j][0] += t.x, acc[k][j][1] += t.y, acc[k][j][2] += t.z, acc[k][j][3] += t.w;
           }
+        }
       }
     }
     if (grp != 0) return;
@@ -472,6 +471,7 @@ inline int launch_fwd(const float* x1, const float* x2, float* out, unsigned* si
   const float inv_c = 1.0f / (float)C;
   if (tiles <= 160 && (C / CC) % 4 == 0 && C / CC >= 8)  // few tiles, >= 2 chunks per group: 4 channel groups per workgroup
     hipLaunchKernelGGL((fwd_kernel<2, 4>), grid, dim3(NT * 4), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
+  // (2 groups at ~1 tile per CU, e.g. 48x80: 23.4 -> 26.1 us -- splitting only pays while CUs are idle)
   else if (tiles >= 768)
     hipLaunchKernelGGL((fwd_kernel<2, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
   else
