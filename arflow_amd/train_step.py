@@ -44,16 +44,13 @@ def synthetic_pairs(batch, height, width, frames=2, device='cuda', seed=0):
 
 
 class TrainStep:
-    def __init__(self, workload, device, lr=1e-4, seed=0, n_buckets=4, channels_last=False):
+    def __init__(self, workload, device, lr=1e-4, seed=0, n_buckets=4):
         mcfg, lcfg = WORKLOADS[workload]
         self.model_cfg, self.loss_cfg = AttrDict(mcfg), AttrDict(lcfg)
         torch.manual_seed(seed)
         self.model = get_model(self.model_cfg)
         self.model.init_weights()
         self.model.to(device).train()
-        self.channels_last = channels_last
-        if channels_last:  # experiment knob: NHWC activations for the MIOpen convolutions
-            self.model.to(memory_format=torch.channels_last)
         self.loss = get_loss(self.loss_cfg)
         import os
         self.reducer = FlatGradAllReduce(self.model, n_buckets=n_buckets,
@@ -68,8 +65,6 @@ class TrainStep:
         self.last = None
 
     def __call__(self, img_pair):
-        if self.channels_last:
-            img_pair = img_pair.contiguous(memory_format=torch.channels_last)
         res = self.model(img_pair, with_bk=True)
         if self.loss_cfg.type == 'mv':
             out = self.loss(res['flows_fw'], res['flows_bw'], img_pair)

@@ -234,7 +234,6 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='image pairs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--channels-last', action='store_true', help='experiment: NHWC activations for MIOpen')
     ap.add_argument('--miopen-find', '--miopen-benchmark', dest='miopen_benchmark', action='store_true',
                     help='let MIOpen time every solver per convolution (slow the first time; results go to MIOPEN_USER_DB_PATH)')
     args = ap.parse_args()
@@ -265,7 +264,7 @@ def main():
     H, W = args.size
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
-    step = TrainStep(args.workload, device, seed=1234, channels_last=args.channels_last)
+    step = TrainStep(args.workload, device, seed=1234)
     torch.manual_seed(1000 + rank)  # level-dropout draws differ per rank, like independent workers
     img = synthetic_pairs(args.batch, H, W, frames=step.model_cfg.get('n_frames', 2), device=device, seed=100 + rank)
 
