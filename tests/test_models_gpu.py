@@ -72,3 +72,25 @@ def test_model_on_hip_ops_matches_reference(golden, case):
     rel = np.abs(got_sum - gsum) / (gabs + 1e-7)
     w = int(np.argmax(rel))
     assert rel[w] <= TOL, 'worst sum(g) mismatch %.3e at %s (got %.6g ref %.6g)' % (rel[w], names[w], got_sum[w], gsum[w])
+
+
+@pytest.mark.gpu
+def test_conv_block_with_fused_epilogue_matches_torch():
+    """blocks.conv(...) (bias-free MIOpen conv + fused bias/LeakyReLU pass) == Conv2d(bias) + LeakyReLU(0.1):
+    output, input gradient, weight and bias gradients; same parameter names as the reference's Sequential."""
+    import torch.nn as nn
+    from arflow_amd.models.blocks import conv
+    torch.manual_seed(3)
+    blk = conv(12, 20, kernel_size=3, stride=2, dilation=1).cuda()
+    assert sorted(blk.state_dict().keys()) == ['0.bias', '0.weight']
+    ref = nn.Sequential(nn.Conv2d(12, 20, 3, stride=2, padding=1), nn.LeakyReLU(0.1)).cuda()
+    ref.load_state_dict(blk.state_dict())
+    x = torch.randn(3, 12, 21, 34, device='cuda')
+    go = torch.randn(3, 20, 11, 17, device='cuda')
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = blk(xa), ref(xb)
+    assert float((ya - yb).abs().max()) <= 1e-5 * float(yb.abs().max())
+    ga = torch.autograd.grad(ya, [xa] + list(blk.parameters()), go)
+    gb = torch.autograd.grad(yb, [xb] + list(ref.parameters()), go)
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
