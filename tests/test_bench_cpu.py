@@ -1,0 +1,41 @@
+"""bench.py helpers that do not need a GPU: the algorithmic-byte formulas and the lookup of
+the PMC traffic table kept under profiles/."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_algorithmic_bytes_follow_the_survey_formulas():
+    import bench
+    B, C, H, W = 16, 32, 96, 160
+    px = B * H * W
+    assert bench.algorithmic_bytes('arflow_corr_fwd', (B, C, H, W, 4)) == 4 * px * (2 * C + 81)
+    assert bench.algorithmic_bytes('arflow_corr_fwd', (B, C, H, W, 4, 3)) == 4 * px * (2 * C + 81 + 3)
+    assert bench.algorithmic_bytes('arflow_corr_bwd', (B, C, H, W, 4, 0)) == 4 * px * (81 + 4 * C)
+    assert bench.algorithmic_bytes('arflow_corr_bwd', (B, C, H, W, 4, 3)) == 4 * px * (81 + 3 + 4 * C)
+    assert bench.algorithmic_bytes('arflow_warp_fwd', (B, C, H, W)) == 4 * px * (2 * C + 2)
+    assert bench.algorithmic_bytes('arflow_warp_bwd', (B, C, H, W, True)) == 4 * px * (3 * C + 4)
+    assert bench.algorithmic_bytes('arflow_warp_bwd', (8, 3, 384, 640, False)) == 4 * 8 * 384 * 640 * (2 * 3 + 4)
+    assert bench.algorithmic_bytes('arflow_census_fwd', (8, 384, 640)) == 4 * 8 * 384 * 640 * 8
+    assert bench.algorithmic_bytes('arflow_featnorm_fwd', (B, C * H * W)) == 16 * B * C * H * W
+    assert bench.algorithmic_bytes('arflow_bias_act_bwd', (B, 128, H * W)) == 12 * B * 128 * H * W
+    assert bench.algorithmic_bytes('no_such_entry', (1,)) == 0
+
+
+def test_pmc_traffic_table_covers_the_benchmark_shapes():
+    import bench
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    table = json.load(open(path))
+    assert all(set(v) >= {'fetch_kb', 'write_kb', 'hbm_bytes'} for v in table.values())
+    shapes = [('arflow_census_bwd', (8, 384, 640)), ('arflow_census_fwd', (8, 384, 640)),
+              ('arflow_corr_fwd', (16, 32, 96, 160, 4, 3)), ('arflow_corr_bwd', (16, 32, 96, 160, 4, 3)),
+              ('arflow_warp_fwd', (16, 32, 96, 160)), ('arflow_warp_bwd', (16, 32, 96, 160, True)),
+              ('arflow_warp_fwd', (8, 3, 384, 640)), ('arflow_warp_bwd', (8, 3, 384, 640, False)),
+              ('arflow_featnorm_fwd', (16, 491520)), ('arflow_featnorm_bwd', (16, 491520))]
+    for name, shape in shapes:
+        t = bench.pmc_traffic(name, shape)
+        a = bench.algorithmic_bytes(name, shape)
+        assert t is not None, (name, shape)
+        assert 0.9 * a <= t <= 2.5 * a, (name, shape, t, a)  # measured HBM traffic within 2.5x of the compulsory bytes
+    assert bench.pmc_traffic('arflow_corr_fwd', (1, 5, 9, 11, 4, 0)) is None  # not a profiled shape
