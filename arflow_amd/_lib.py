@@ -57,6 +57,10 @@ def load():
         raise ArflowHipError(
             'libarflow_hip.so not found at %s: the HIP extension is not built and there is no CPU '
             'fallback.  Run `make -C arflow_amd/csrc` (or __graft_entry__.build()).' % LIB_PATH)
+    # torch first: the library must bind to the HIP runtime PyTorch has loaded (the one that owns the device
+    # memory and streams it is handed).  Loaded ahead of torch it pulls in the system runtime instead and the
+    # process ends up with two: launches then fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

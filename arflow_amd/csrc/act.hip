@@ -73,6 +73,7 @@ __global__ __launch_bounds__(NT) void bias_act_bwd_kernel(const float* gout, con
 
 extern "C" int arflow_bias_act_fwd(const float* x, const float* bias, float* y, int B, int C, long HW,
                                    float negative_slope, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(x);
   AF_REQUIRE_PTR(y);
   AF_REQUIRE(B > 0 && C > 0 && HW > 0 && B <= 65535 && C <= 65535, ARFLOW_ESHAPE);
@@ -83,6 +84,7 @@ extern "C" int arflow_bias_act_fwd(const float* x, const float* bias, float* y, 
 
 extern "C" int arflow_bias_act_bwd(const float* gout, const float* y, float* gin, float* gbias, int B, int C, long HW,
                                    float negative_slope, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(gout);
   AF_REQUIRE_PTR(y);
   AF_REQUIRE_PTR(gin);

@@ -15,6 +15,12 @@
     if (!(cond)) return (code); \
   } while (0)
 
+// hipGetLastError() reports (and clears) the last error of ANY runtime call on this host thread, including
+// benign failures of the framework's own probing (seen: hipErrorNoDevice left behind before the first launch
+// when the library was loaded ahead of the framework's device initialisation).  Every entry point drops such
+// a stale code first, so that af_launch_status() reports only what its own launches produced.
+static inline void af_clear_stale_error() { (void)hipGetLastError(); }
+
 static inline int af_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ARFLOW_OK : (ARFLOW_ELAUNCH_BASE - (int)e);

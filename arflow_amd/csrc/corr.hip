@@ -353,6 +353,7 @@ extern "C" int arflow_corr_sign_planes(int C, int W, int max_disp) {
 
 extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C,
                                int H, int W, int max_disp, float negative_slope, arflow_stream_t stream) {
+  af_clear_stale_error();
   const float slope = negative_slope;
   AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
@@ -381,6 +382,7 @@ extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, uns
 extern "C" int arflow_corr_bwd(const float* gout, const float* out, const unsigned* sign_bits, const float* x1,
                                const float* x2, float* gx1, float* gx2, int B, int C, int H, int W, int max_disp,
                                float negative_slope, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(gout);
   const float slope = negative_slope;
   const bool act = negative_slope != 1.0f;

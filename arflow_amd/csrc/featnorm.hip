@@ -352,6 +352,7 @@ inline unsigned blocks_per_sample(int B, long n, int floats_per_block) {
 
 extern "C" int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, float* y2, double* acc, float* stats,
                                    int B, long n, int mode, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
   AF_REQUIRE_PTR(y1);
@@ -376,6 +377,7 @@ extern "C" int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, 
 extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float* x1, const float* x2,
                                    const float* stats, double* acc, float* gx1, float* gx2, int B, long n, int mode,
                                    arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(g1);
   AF_REQUIRE_PTR(g2);
   AF_REQUIRE_PTR(x1);

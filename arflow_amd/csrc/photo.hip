@@ -782,6 +782,7 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ im, c
 extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const float* mask, float* ham,
                                  float* dham, float* sums, int B, int H, int W, int radius,
                                  arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(im_a);
   AF_REQUIRE_PTR(im_b);
   AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 8 * 65535, ARFLOW_ESHAPE);
@@ -813,6 +814,7 @@ extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const flo
 
 extern "C" int arflow_census_bwd(const float* im_a, const float* im_b, const float* gham, const float* scale,
                                  float* g_im_b, int B, int H, int W, int radius, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(im_a);
   AF_REQUIRE_PTR(im_b);
   AF_REQUIRE_PTR(gham);
@@ -841,6 +843,7 @@ extern "C" int arflow_census_bwd(const float* im_a, const float* im_b, const flo
 
 extern "C" int arflow_photo_fwd(const float* im, const float* recons, const float* mask, float* ssim_map,
                                 float* sums, int B, int C, int H, int W, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(im);
   AF_REQUIRE_PTR(recons);
   AF_REQUIRE_PTR(sums);
@@ -862,6 +865,7 @@ extern "C" int arflow_photo_fwd(const float* im, const float* recons, const floa
 extern "C" int arflow_photo_bwd(const float* im, const float* recons, const float* mask, const float* gmap,
                                 const float* coef, float* g_recons, int B, int C, int H, int W,
                                 arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(im);
   AF_REQUIRE_PTR(recons);
   AF_REQUIRE_PTR(coef);

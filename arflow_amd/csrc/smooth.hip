@@ -194,6 +194,7 @@ int check_smooth(const float* flow, const float* img, int B, int Ci, int H, int 
 extern "C" int arflow_smooth_fwd(const float* flow, const float* img, float* sums, int B, int Ci, int H,
                                  int W, long flow_bstride, float flow_scale, float alpha, int order,
                                  int wmode, int penalty, arflow_stream_t stream) {
+  af_clear_stale_error();
   int rc = check_smooth(flow, img, B, Ci, H, W, flow_bstride, order, wmode, penalty);
   if (rc) return rc;
   AF_REQUIRE_PTR(sums);
@@ -214,6 +215,7 @@ extern "C" int arflow_smooth_fwd(const float* flow, const float* img, float* sum
 extern "C" int arflow_smooth_bwd(const float* flow, const float* img, const float* coef, float* gflow, int B,
                                  int Ci, int H, int W, long flow_bstride, float flow_scale, float alpha,
                                  int order, int wmode, int penalty, arflow_stream_t stream) {
+  af_clear_stale_error();
   int rc = check_smooth(flow, img, B, Ci, H, W, flow_bstride, order, wmode, penalty);
   if (rc) return rc;
   AF_REQUIRE_PTR(coef);
@@ -227,6 +229,7 @@ extern "C" int arflow_smooth_bwd(const float* flow, const float* img, const floa
 }
 
 extern "C" int arflow_down4(const float* in, float* out, int planes, int H, int W, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(in);
   AF_REQUIRE_PTR(out);
   AF_REQUIRE(planes > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && planes <= 65535, ARFLOW_ESHAPE);
@@ -237,6 +240,7 @@ extern "C" int arflow_down4(const float* in, float* out, int planes, int H, int 
 
 extern "C" int arflow_up4_clamp_mul(const float* in, const float* valid, float* out, int B, int h, int w,
                                     arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(in);
   AF_REQUIRE_PTR(out);
   AF_REQUIRE(B > 0 && h > 0 && w > 0 && B <= 65535 && 4 * h <= 65535, ARFLOW_ESHAPE);

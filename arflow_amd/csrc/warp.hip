@@ -727,6 +727,7 @@ inline int pick_bx(int W) { return W >= 192 ? 256 : (W >= 96 ? 128 : 64); }
 extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, float* valid, int B, int C,
                                int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode,
                                int align_corners, int norm_mode, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(src);
   AF_REQUIRE_PTR(flow);
   AF_REQUIRE_PTR(out);
@@ -749,6 +750,7 @@ extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, 
 extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float* flow, float* gsrc,
                                float* gflow, int B, int C, int Hs, int Ws, int H, int W, long flow_bstride,
                                int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(gout);
   AF_REQUIRE_PTR(src);
   AF_REQUIRE_PTR(flow);
@@ -785,6 +787,7 @@ extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float*
 
 extern "C" int arflow_splat_map(const float* flow, float* out, int B, int H, int W, long flow_bstride,
                                 int variant, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(flow);
   AF_REQUIRE_PTR(out);
   AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
@@ -801,6 +804,7 @@ extern "C" int arflow_splat_map(const float* flow, float* out, int B, int H, int
 
 extern "C" int arflow_coord_mask(const float* flow, float* out, int B, int H, int W, long flow_bstride,
                                  int mode, arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(flow);
   AF_REQUIRE_PTR(out);
   AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
@@ -815,6 +819,7 @@ extern "C" int arflow_coord_mask(const float* flow, float* out, int B, int H, in
 extern "C" int arflow_occ_bidir(const float* flow12, const float* flow21, float* out, int B, int H, int W,
                                 long bstride12, long bstride21, float scale, float bias,
                                 arflow_stream_t stream) {
+  af_clear_stale_error();
   AF_REQUIRE_PTR(flow12);
   AF_REQUIRE_PTR(flow21);
   AF_REQUIRE_PTR(out);
