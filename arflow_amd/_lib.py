@@ -18,6 +18,7 @@ c_f = ctypes.c_float
 # name -> argtypes, exactly the prototypes of include/arflow_hip.h
 PROTOTYPES = {
     'arflow_abi_version': [],
+    'arflow_take_stale_error': [],
     'arflow_corr_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_corr_sign_planes': [c_i, c_i, c_i],
     'arflow_corr_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
@@ -40,7 +41,7 @@ PROTOTYPES = {
     'arflow_up4_clamp_mul': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

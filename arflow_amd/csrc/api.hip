@@ -1,6 +1,26 @@
 #include "common.hpp"
 
-extern "C" int arflow_abi_version(void) { return 6; }
+#include <atomic>
+#include <cstdio>
+
+extern "C" int arflow_abi_version(void) { return 7; }
+
+// A HIP error that was already pending on the calling thread when an entry point was entered (left behind by
+// the framework or by an earlier, unchecked call).  Kept, not dropped: first one is reported once on stderr.
+static std::atomic<int> g_stale_code{0};
+static std::atomic<bool> g_stale_reported{false};
+
+void af_record_stale_error(int code) {
+  int expected = 0;
+  g_stale_code.compare_exchange_strong(expected, code);  // keep the FIRST one until the host takes it
+  if (!g_stale_reported.exchange(true))
+    std::fprintf(stderr,
+                 "libarflow_hip: a HIP error was already pending when an arflow entry point was called: %s (%d). "
+                 "It is NOT from this library's launch; read it with arflow_take_stale_error().\n",
+                 hipGetErrorString((hipError_t)code), code);
+}
+
+extern "C" int arflow_take_stale_error(void) { return g_stale_code.exchange(0); }
 
 extern "C" const char* arflow_strerror(int code) {
   switch (code) {

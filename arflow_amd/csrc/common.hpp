@@ -15,11 +15,22 @@
     if (!(cond)) return (code); \
   } while (0)
 
-// hipGetLastError() reports (and clears) the last error of ANY runtime call on this host thread, including
-// benign failures of the framework's own probing (seen: hipErrorNoDevice left behind before the first launch
-// when the library was loaded ahead of the framework's device initialisation).  Every entry point drops such
-// a stale code first, so that af_launch_status() reports only what its own launches produced.
-static inline void af_clear_stale_error() { (void)hipGetLastError(); }
+// hipGetLastError() reports (and clears) the last error of ANY runtime call on this host thread.  An entry
+// point must not blame its own launches for an error that was already pending when it was called, and must not
+// silently drop that error either: the pending code is moved into a process-wide slot that the host can read
+// (and clear) with arflow_take_stale_error(), and the first one is reported once on stderr.
+extern "C" int arflow_take_stale_error(void);
+void af_record_stale_error(int code);  // api.hip
+static inline void af_clear_stale_error() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) af_record_stale_error((int)e);
+}
+// after every launch of a multi-launch entry point except the last (HIP keeps only the LAST call's status)
+#define AF_LAUNCH_CHECK()                \
+  do {                                   \
+    const int rc_ = af_launch_status();  \
+    if (rc_ != ARFLOW_OK) return rc_;    \
+  } while (0)
 
 static inline int af_launch_status() {
   hipError_t e = hipGetLastError();

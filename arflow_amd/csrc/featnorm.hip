@@ -369,6 +369,7 @@ extern "C" int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, 
   hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 4 * NSLOT * (size_t)B, st);
   if (e != hipSuccess) return af_hip_status(e);
   hipLaunchKernelGGL(moment_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, x1, x2, acc, n);
+  AF_LAUNCH_CHECK();
   hipLaunchKernelGGL(apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, x1, x2, y1, y2, acc, stats, n,
                      mode);
   return af_launch_status();
@@ -396,6 +397,7 @@ extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float
   if (e != hipSuccess) return af_hip_status(e);
   hipLaunchKernelGGL(bwd_sum_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
                      n);
+  AF_LAUNCH_CHECK();
   hipLaunchKernelGGL(bwd_apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
                      gx1, gx2, n, mode);
   return af_launch_status();

@@ -770,6 +770,7 @@ extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float*
   if (gsrc)
     hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
                        flow, gsrc, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  if (gsrc && gflow) AF_LAUNCH_CHECK();
   if (gflow) {
     if (nsplit > 1) {
       hipError_t e = hipMemsetAsync(gflow, 0, sizeof(float) * (size_t)B * 2 * H * W, st);

@@ -64,18 +64,26 @@ class FlatGradAllReduce:
         self._use_avg = self._active and dist.get_backend(process_group) == 'nccl'
         self.reset()
 
+    def _launch(self, bi):
+        s, e, _ = self.buckets[bi]
+        op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        self._handles.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
+
     def _make_hook(self, bi):
         def hook(param):
             self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                s, e, _ = self.buckets[bi]
-                op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
-                self._handles.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
+            # RCCL/NCCL pair collectives across ranks by ISSUE ORDER: buckets are therefore launched strictly in
+            # index order on every rank, whatever order autograd happens to finish them in (a parameter unused on
+            # one rank, a data-dependent branch).  A finished bucket waits until all lower ones have been issued.
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
         return hook
 
     def reset(self):
         self._pending = [len(m) for _, _, m in self.buckets]
         self._handles = []
+        self._next = 0  # lowest bucket not yet issued
 
     def zero_grad(self):
         """One memset instead of one per parameter; keeps ``param.grad`` aliased to the flat buffer."""
@@ -90,10 +98,9 @@ class FlatGradAllReduce:
         received no gradient this step), leaving the averaged gradient in ``param.grad``."""
         if not self._active:
             return
-        for bi, (s, e, _) in enumerate(self.buckets):
-            if self._pending[bi] != 0:  # some parameter got no gradient: reduce the bucket now
-                op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
-                self._handles.append(dist.all_reduce(self.flat[s:e], op=op, group=self.group, async_op=True))
+        while self._next < len(self.buckets):  # buckets holding a parameter that got no gradient: same order
+            self._launch(self._next)
+            self._next += 1
         for h in self._handles:
             h.wait()
         if not self._use_avg:
@@ -105,3 +112,40 @@ class FlatGradAllReduce:
             return
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
+
+
+# ------------------------------------------------------------------------------------------------
+# Global loss normalisation.  The reference computes the loss on the GATHERED batch
+# (trainer/uflow_trainer.py:48-54) and divides by the global sum of the mask (utils/uflow_utils.py:293) or
+# its global mean (losses/flow_loss.py:27).  With a sharded batch a rank only sees its own mask sum M_r;
+# the loss terms ask `global_denominator(M_r)` for the quantity to divide by instead:
+#       off (default)  ->  M_r                      (per-rank normalisation, no communication)
+#       on             ->  (sum_r M_r) / world      (one scalar all-reduce, no gradient)
+# so that the AVERAGE over ranks of  N_r / (sum_r M_r / world)  is  (sum_r N_r) / (sum_r M_r): the
+# gradient all-reduce(AVG) then yields exactly the gradient of the gathered-batch loss.  (Additive epsilons
+# such as census_loss's 1e-6 are divided by `world` by the caller through `world_size()`.)
+_global_norm_group = None
+_global_norm_on = False
+
+
+def enable_global_loss_norm(on=True, process_group=None):
+    global _global_norm_on, _global_norm_group
+    _global_norm_on = bool(on) and dist.is_available() and dist.is_initialized()
+    _global_norm_group = process_group
+
+
+def global_loss_norm_enabled():
+    return _global_norm_on
+
+
+def world_size():
+    return dist.get_world_size(_global_norm_group) if _global_norm_on else 1
+
+
+def global_denominator(local_sum):
+    """local mask sum (0-d or 1-element tensor, no grad) -> its mean over ranks when global normalisation is on."""
+    if not _global_norm_on:
+        return local_sum
+    t = local_sum.detach().clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_global_norm_group)
+    return t / dist.get_world_size(_global_norm_group)

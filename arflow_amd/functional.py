@@ -7,6 +7,7 @@ allocator and kernels are enqueued on ``torch.cuda.current_stream()`` -- no sync
 import torch
 
 from . import _lib
+from . import ddp as _ddp
 
 PAD = {'zeros': 0, 'border': 1}
 NORM_ARFLOW, NORM_UFLOW = 0, 1
@@ -353,10 +354,13 @@ class CensusLossFunction(torch.autograd.Function):
             _call('arflow_census_fwd', _p(im_a), _p(im_b), _p(mask), None, _p(dham), _p(buf), B, H, W, r, _stream(),
                   key=(B, H, W))
         sums = _fold_sums(buf, 2)
-        inv = 1.0 / (sums[1] + 1e-6)
+        # sharded batch + global normalisation: divide by the mask sum of ALL ranks (ddp.global_denominator);
+        # identity when that is off (the default)
+        den = _ddp.global_denominator(sums[1]) + 1e-6 / _ddp.world_size()
+        inv = 1.0 / den
         ctx.save_for_backward(im_a, im_b, dham, inv)
         ctx.r = r
-        return sums[0] / (sums[1] + 1e-6)
+        return sums[0] * inv
 
     @staticmethod
     def backward(ctx, gloss):

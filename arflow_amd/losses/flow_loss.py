@@ -5,6 +5,7 @@ import torch.nn.functional as F
 
 from .. import functional as AF
 from ..loss_blocks import smooth_grad_1st, smooth_grad_2nd
+from ..ddp import global_denominator
 from ..warp_utils import flow_warp, get_occu_mask_backward, get_occu_mask_bidirection
 
 
@@ -27,7 +28,8 @@ class unFlowLoss(nn.Module):
             total = total + cfg.w_l1 * s[0] / float(b * c * h * w)
         if cfg.w_ssim > 0:
             total = total + cfg.w_ssim * s[1] / float(b * c * (h - 2) * (w - 2))
-        return total / (s[2] / float(b * h * w))
+        # mask.mean() of the gathered batch when global normalisation is on (ddp.global_denominator), else this rank's
+        return total / (global_denominator(s[2]) / float(b * h * w))
 
     def loss_smooth(self, flow, im1_scaled, scale):
         cfg = self.cfg

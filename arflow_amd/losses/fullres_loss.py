@@ -6,6 +6,7 @@ import torch.nn.functional as F
 
 from .. import functional as AF
 from ..loss_blocks import SSIM, TernaryLoss, penalty_ddflow, smooth_grad_1st
+from ..ddp import global_denominator, world_size
 from ..warp_utils import (border_mask, compute_range_map, flow_warp, get_occu_mask_backward,
                           get_occu_mask_bidirection)
 
@@ -19,14 +20,14 @@ class FullResLoss(nn.Module):
         cfg = self.cfg
         loss = 0
         if cfg.w_l1 > 0:
-            loss = loss + torch.sum(cfg.w_l1 * (im - recons).abs() * mask) / (torch.sum(mask) + 1e-6)
+            loss = loss + torch.sum(cfg.w_l1 * (im - recons).abs() * mask) / (global_denominator(torch.sum(mask)) + 1e-6 / world_size())
         if cfg.w_ssim > 0:
             # shape mismatch in the reference too (fullres_loss.py:22): un-padded SSIM x full mask
-            loss = loss + torch.sum(cfg.w_ssim * SSIM(recons, im) * mask) / (torch.sum(mask) + 1e-6)
+            loss = loss + torch.sum(cfg.w_ssim * SSIM(recons, im) * mask) / (global_denominator(torch.sum(mask)) + 1e-6 / world_size())
         if cfg.w_ternary > 0:
             dist, valid = TernaryLoss(im, recons, max_distance=cfg.ternary_distance, sum_dist=True)
             m = torch.detach(valid * mask)
-            loss = loss + torch.sum(cfg.w_ternary * penalty_ddflow(dist) * m) / (torch.sum(m) + 1e-6)
+            loss = loss + torch.sum(cfg.w_ternary * penalty_ddflow(dist) * m) / (global_denominator(torch.sum(m)) + 1e-6 / world_size())
         return loss
 
     def loss_smooth(self, flow, im):

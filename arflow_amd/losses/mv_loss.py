@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as AF
+from ..ddp import global_denominator
 from ..warp_utils import border_mask, flow_warp
 
 
@@ -50,7 +51,7 @@ class MvLoss(nn.Module):
                     photo = photo + cfg.w_l1 * sums[0] / float(b * 3 * h * w)
                 if cfg.w_ssim > 0:
                     photo = photo + cfg.w_ssim * sums[1] / float(b * 3 * (h - 2) * (w - 2))
-                l_warp = l_warp + photo / (sums[2] / float(b * h * w) + 1e-6)
+                l_warp = l_warp + photo / (global_denominator(sums[2]) / float(b * h * w) + 1e-6)
                 if cfg.w_sm_scales[i] != 0:
                     sm = AF.smooth_sums(flow, i1, 1.0 / s, cfg.alpha, 1, 0, 0)
                     l_smooth = l_smooth + (sm[0] / float(b * 2 * h * (w - 1)) / 2.) / 2. + \

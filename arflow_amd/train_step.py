@@ -56,6 +56,9 @@ class TrainStep:
         self.reducer = FlatGradAllReduce(self.model, n_buckets=n_buckets,
                                          force_collectives=os.environ.get('ARFLOW_FORCE_COLLECTIVES') == '1')
         self.reducer.broadcast_parameters(0)
+        # optional gathered-batch loss normalisation (one scalar all-reduce per masked term)
+        from . import ddp
+        ddp.enable_global_loss_norm(os.environ.get('ARFLOW_GLOBAL_LOSS_NORM') == '1')
         # Adam, lr 1e-4, betas (0.9, 0.999), eps 1e-8, no decay: configs/chairs_uflow.json:29-48
         kw = dict(lr=lr, betas=(0.9, 0.999), eps=1e-8)
         try:

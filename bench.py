@@ -10,8 +10,13 @@ gradient all-reduce (N > 1) and the Adam update.  Default workload = BASELINE.js
 384x640 pairs, batch 8 per GPU (weak scaling), fp32.  Inputs are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
-For N > 1 launch with:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-                        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+N > 1: either launched by  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 --master-port P bench.py --gpus N ...  (one rank per GPU, RCCL), or plainly as  python bench.py
+--gpus N : it then starts those N ranks itself as child processes and relays rank 0's line.  With fewer
+GPUs than ranks the ranks share devices and reduce over gloo (a rehearsal: "oversubscribed": true).
+ARFLOW_FORCE_COLLECTIVES=1 runs the bucketed all-reduce path at world size 1 over RCCL.
+ARFLOW_GLOBAL_LOSS_NORM=1 normalises the loss by the GLOBAL mask sums (one extra scalar all-reduce per
+census/photometric term), the reference's gathered-batch semantics (trainer/uflow_trainer.py:48-54).
 """
 import argparse
 import gc
@@ -224,6 +229,32 @@ def cpu_baseline(workload, height, width, budget_s=25.0):
                       '%d timed step(s) after 1 warm-up, torch threads=%d' % (workload, B, height, width, len(times), cores)}
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` from a plain shell: start N ranks as CHILD processes through
+    torch.distributed.run (never an exec of this process), relay rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+        sys.stdout.flush()
+    if proc.returncode != 0:
+        return proc.returncode
+    return 0 if lines else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -238,25 +269,34 @@ def main():
                     help='let MIOpen time every solver per convolution (slow the first time; results go to MIOPEN_USER_DB_PATH)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(_self_launch(args.gpus))  # before anything touches the GPU: the ranks are fresh child processes
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched through torch.distributed.run with %d ranks '
-                     '(see the module docstring)' % (args.gpus, args.gpus))
-        args.gpus = world
-    if not torch.cuda.is_available():
+    args.gpus = world
+    n_dev = torch.cuda.device_count()  # does not initialise the GPU
+    if n_dev == 0 or not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # Fewer GPUs than ranks (a rehearsal of the N-rank launch path on a smaller box): ranks share devices and
+    # the collectives go over gloo, because RCCL refuses two ranks on one device.  The line says so
+    # ("oversubscribed": true) -- such a run checks the launch/reduction path, it is not a scaling number.
+    oversub = world > n_dev
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     use_dist = world > 1 or os.environ.get('ARFLOW_FORCE_COLLECTIVES') == '1'
+    backend = 'gloo' if oversub else 'nccl'
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group(backend='nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=device)
+        else:
+            dist.init_process_group(backend='gloo')
 
     from arflow_amd import functional as AF
     from arflow_amd.train_step import TrainStep, synthetic_pairs
@@ -297,10 +337,14 @@ def main():
     timing = AF.stop_kernel_timing() if not args.no_kernel_timing else {}
     finite = bool(torch.isfinite(step.last).item())
 
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    per_rank_ms = [1e3 * elapsed / args.steps]
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        # gloo reduces host tensors; nccl (RCCL) device tensors
+        tdev = device if backend == 'nccl' else 'cpu'
+        every = [torch.zeros(1, device=tdev, dtype=torch.float64) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, torch.tensor([elapsed], device=tdev, dtype=torch.float64))
+        per_rank_ms = [1e3 * float(e.item()) / args.steps for e in every]
+        elapsed = max(float(e.item()) for e in every)  # MAX over ranks
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -313,6 +357,12 @@ def main():
                                    % (args.workload, H, W, args.batch),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'loss_finite': finite},
+            # ranks that took part in the gradient all-reduce and the backend that carried it ('nccl' = RCCL)
+            'rccl_ranks': dist.get_world_size() if use_dist else 0,
+            'collective_backend': backend if use_dist else None,
+            'oversubscribed': bool(oversub),
+            'global_loss_norm': os.environ.get('ARFLOW_GLOBAL_LOSS_NORM') == '1',
+            'per_rank_ms_per_step': per_rank_ms,
         }
         # dominant hot-path kernel by accumulated device time (HIP events around every launch).  The conv
         # epilogue (bias + LeakyReLU) of the host model also goes through the C ABI but is not on the

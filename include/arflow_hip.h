@@ -61,6 +61,12 @@ typedef void* arflow_stream_t; /* hipStream_t */
 
 int arflow_abi_version(void);
 const char* arflow_strerror(int code);
+/* HIP keeps ONE "last error" per host thread.  If a code was already pending when an entry point is entered
+ * (left by the host framework or an unchecked earlier call) it is not attributed to this library's launch and
+ * not dropped either: the first such hipError_t is kept (and reported once on stderr) until the host reads it
+ * here.  Returns that hipError_t (0 = none) and clears the slot.  [No reference counterpart: the reference
+ * checks cudaGetLastError() once after its launches, correlation_cuda_kernel.cu:383-392.] */
+int arflow_take_stale_error(void);
 
 /* ---- cost volume ------------------------------------------------------------------------------
  * out[b, i*(2d+1)+j, y, x] = (1/C) sum_c x1[b,c,y,x] * x2[b,c,y+i-d,x+j-d], zero outside.

@@ -65,9 +65,12 @@ def assert_close(actual, expected, atol, rtol, msg=''):
     assert actual.shape == expected.shape, '%s shape %s vs %s' % (msg, tuple(actual.shape), tuple(expected.shape))
     err = (actual - expected).abs()
     tol = atol + rtol * expected.abs()
-    bad = err > tol
+    # `~(err <= tol)` and not `err > tol`: a NaN/Inf in `actual` compares False either way round, and must count
+    # as a mismatch (tests/test_bench_cpu.py::test_assert_close_rejects_nan pins this)
+    bad = ~(err <= tol)
     if bad.any():
-        i = int(torch.argmax(err - tol))
+        i = int(torch.argmax(torch.where(bad, torch.nan_to_num(err - tol, nan=float('inf'), posinf=float('inf')),
+                                         torch.full_like(err, -1.0))))
         raise AssertionError('%s: %d/%d elements out of tolerance (atol=%g rtol=%g); worst |err|=%.3e at flat %d '
                              '(actual %.8g expected %.8g)' % (msg, int(bad.sum()), bad.numel(), atol, rtol,
                                                              float(err.flatten()[i]), i,

@@ -39,3 +39,19 @@ def test_pmc_traffic_table_covers_the_benchmark_shapes():
         assert t is not None, (name, shape)
         assert 0.9 * a <= t <= 2.5 * a, (name, shape, t, a)  # measured HBM traffic within 2.5x of the compulsory bytes
     assert bench.pmc_traffic('arflow_corr_fwd', (1, 5, 9, 11, 4, 0)) is None  # not a profiled shape
+
+
+def test_assert_close_rejects_nan():
+    """A kernel returning NaN/Inf must fail every parity test: `err > tol` is False for NaN."""
+    import pytest
+    import torch
+    from tests.conftest import assert_close
+    ref = torch.ones(4, 5)
+    assert_close(ref.clone(), ref, 1e-6, 1e-6)
+    for poison in (float('nan'), float('inf'), -float('inf')):
+        bad = ref.clone()
+        bad[2, 3] = poison
+        with pytest.raises(AssertionError):
+            assert_close(bad, ref, 1e-6, 1e-6, 'poisoned')
+    with pytest.raises(AssertionError):
+        assert_close(ref + 1e-3, ref, 1e-6, 1e-6)

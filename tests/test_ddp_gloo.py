@@ -105,6 +105,83 @@ def _worker_model(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_order(rank, world, port, q):
+    """One rank skips a parameter (data-dependent branch): autograd finishes the buckets in a different order
+    on the two ranks.  Collectives pair by issue order, so the reducer must still issue them in index order
+    (ADVICE r1): with completion-order launches the differently sized buckets pair up -> error or garbage."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from arflow_amd.ddp import FlatGradAllReduce
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 7), torch.nn.Linear(4, 2)
+    net = torch.nn.ModuleList([a, b, c])
+    red = FlatGradAllReduce(net, n_buckets=3)
+    red.broadcast_parameters(0)
+    assert len(red.buckets) >= 2 and len({e - s for s, e, _ in red.buckets}) == len(red.buckets)  # all sizes differ
+    x = torch.ones(3, 4) * (rank + 1)
+    red.zero_grad()
+    # rank 0 uses (a, c) only, rank 1 uses all three and touches them in the opposite order
+    out = a(x).sum() + c(x).sum() if rank == 0 else c(x).sum() * 2 + b(x).sum() + a(x).sum()
+    out.backward()
+    red.finish()
+    # expected: mean over ranks of the analytic gradients (d sum(Wx+b) / dW = column sums of x)
+    def lin_grad(n_out, xs, scale):
+        return torch.cat([(scale * xs.sum(0)).repeat(n_out, 1).flatten(), scale * torch.full((n_out,), float(xs.shape[0]))])
+    x0, x1 = torch.ones(3, 4), torch.ones(3, 4) * 2
+    exp = {0: (lin_grad(4, x0, 1) + lin_grad(4, x1, 1)) / 2, 1: (lin_grad(7, x1, 1)) / 2,
+           2: (lin_grad(2, x0, 1) + lin_grad(2, x1, 2)) / 2}
+    for i, m in enumerate((a, b, c)):
+        got = torch.cat([m.weight.grad.flatten(), m.bias.grad.flatten()])
+        assert torch.allclose(got, exp[i], atol=1e-6), 'module %d: %s vs %s' % (i, got, exp[i])
+    q.put((rank, 'ok'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _worker_global_norm(rank, world, port, q):
+    """ddp.global_denominator: the rank-average of N_r / (global_denominator(M_r) + eps / world) is the
+    gathered-batch loss  sum N_r / (sum M_r + eps)  (utils/uflow_utils.py:293 on the batch the reference's
+    trainer gathers, trainer/uflow_trainer.py:48-54), and so is the averaged gradient."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from arflow_amd import ddp
+    from arflow_amd.ddp import FlatGradAllReduce
+    g = torch.Generator().manual_seed(3)
+    x_all = torch.rand(4, 1, 6, 6, generator=g)
+    m_all = (torch.rand(4, 1, 6, 6, generator=g) > (0.2 + 0.15 * torch.arange(4).view(4, 1, 1, 1))).float()  # unequal mask sums
+    torch.manual_seed(0)
+    net = torch.nn.Conv2d(1, 1, 3, padding=1)
+    red = FlatGradAllReduce(net, n_buckets=1)
+    red.broadcast_parameters(0)
+
+    def masked_loss(m, x, mask, normaliser, eps):
+        num = (m(x).abs() * mask).sum()
+        return num / (normaliser(mask.sum()) + eps)
+
+    # single process, gathered batch
+    import copy
+    ref = copy.deepcopy(net)
+    l_ref = masked_loss(ref, x_all, m_all, lambda s: s, 1e-6)
+    g_ref = torch.autograd.grad(l_ref, list(ref.parameters()))
+    sl = slice(2 * rank, 2 * rank + 2)
+    res = {}
+    for on in (False, True):
+        ddp.enable_global_loss_norm(on)
+        assert ddp.world_size() == (world if on else 1)
+        red.zero_grad()
+        l = masked_loss(net, x_all[sl], m_all[sl], ddp.global_denominator, 1e-6 / ddp.world_size())
+        l.backward()
+        red.finish()
+        lt = l.detach().clone()
+        dist.all_reduce(lt)
+        gerr = max(float((p.grad - gr).abs().max()) for p, gr in zip(net.parameters(), g_ref))
+        res[on] = (abs(float(lt / world - l_ref)), gerr)
+    ddp.enable_global_loss_norm(False)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _run(worker, n=2):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -131,3 +208,17 @@ def test_batch_sharding_reproduces_single_process_gradient():
     out = _run(_worker_model)
     assert out and out[0][0] == 'model'
     assert out[0][1] < 1e-5, 'sharded gradient differs from the single-process one: rel err %g' % out[0][1]
+
+
+def test_buckets_are_issued_in_index_order_when_ranks_disagree():
+    out = _run(_worker_order)
+    assert sorted(r for r, _ in out) == [0, 1]
+
+
+def test_global_loss_normalisation_matches_gathered_batch():
+    out = _run(_worker_global_norm)
+    assert len(out) == 2
+    for _, res in out:
+        assert res[True][0] < 1e-6 and res[True][1] < 1e-6, 'global normalisation differs from the gathered batch: %s' % (res,)
+        # per-rank normalisation (the default) is measurably different on unequal masks: the flag does something
+        assert res[False][1] > 1e-4
