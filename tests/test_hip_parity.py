@@ -320,9 +320,20 @@ def test_masks_golden(golden):
         assert torch.equal(got[safe], g[name + '_occ_back_02'][safe]), name + ' occ back'
         assert_close(WU.border_mask(fl), g[name + '_border_mask'], 0, 0, name + ' border mask')
         for key, other in (('_occ_bidir', -0.7 * fl.flip(-1)), ('_occ_bidir_neg', -fl)):
-            got = WU.get_occu_mask_bidirection(fl, other.contiguous()).cpu()
+            other = other.contiguous()
+            got = WU.get_occu_mask_bidirection(fl, other).cpu()
             ref = g[name + key]
-            assert float((got != ref).float().mean()) <= 0.01, name + key  # threshold ties may flip a pixel
+            # thresholded: |f12 + f21w|^2 > 0.01 (|f12|^2 + |f21w|^2) + 0.5 (utils/warp_utils.py:93-100).  Compare
+            # exactly wherever the oracle's margin to the threshold exceeds the fp32 noise of the warp (1e-4
+            # relative), as for the range-map masks above; inside that band either side is right.
+            from oracle import ops as O_
+            f12, f21 = fl.cpu(), other.cpu()
+            f21w = O_.flow_warp(f21, f12, pad='zeros')
+            lhs = ((f12 + f21w) ** 2).sum(1, keepdim=True)
+            rhs = 0.01 * ((f12 ** 2).sum(1, keepdim=True) + (f21w ** 2).sum(1, keepdim=True)) + 0.5
+            safe = (lhs - rhs).abs() > 1e-4 * (lhs + rhs)
+            assert float(safe.float().mean()) > 0.97, name + key
+            assert torch.equal(got[safe], ref[safe]), name + key
 
 
 def test_photo_blocks_golden(golden):
@@ -335,8 +346,11 @@ def test_photo_blocks_golden(golden):
         # sigma = E[x^2]-mu^2 cancels against C2 = 9e-4: fp32 summation-order noise is amplified ~1e3x
         assert_close(y, g[name + '_ssim'], 5e-5, 1e-5, name + ' ssim')
         ga, gb = torch.autograd.grad(y, [a, b], cu(g[name + '_ssim_g']))
-        assert_close(ga, g[name + '_ssim_ga'], 5e-4, 1e-3, name + ' ssim ga')
-        assert_close(gb, g[name + '_ssim_gb'], 5e-4, 1e-3, name + ' ssim gb')
+        # relative to the gradient's scale: 2e-4 of max|ref| (the window variances cancel against C2 = 9e-4, which
+        # amplifies fp32 summation-order noise ~1e2 on the flattest windows) + 1e-3 of the element
+        for got_, key in ((ga, '_ssim_ga'), (gb, '_ssim_gb')):
+            ref_ = g[name + key]
+            assert_close(got_, ref_, 2e-4 * float(ref_.abs().max()), 1e-3, name + key)
         for md, sd in ((1, False), (3, True)):
             tag = '%s_ternary_%d_%d' % (name, md, int(sd))
             a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
@@ -344,8 +358,9 @@ def test_photo_blocks_golden(golden):
             assert_close(dist, g[tag + '_dist'], 2e-5, 2e-5, tag)
             assert_close(tm, g[tag + '_mask'], 0, 0, tag + ' mask')
             ga, gb = torch.autograd.grad(dist, [a, b], cu(g[tag + '_g']))
-            assert_close(ga, g[tag + '_ga'], 2e-3, 2e-4, tag + ' ga')
-            assert_close(gb, g[tag + '_gb'], 2e-3, 2e-4, tag + ' gb')
+            for got_, key in ((ga, '_ga'), (gb, '_gb')):  # relative to the gradient's scale, not an absolute number
+                ref_ = g[tag + key]
+                assert_close(got_, ref_, 1e-4 * float(ref_.abs().max()), 2e-4, tag + key)
         for ps in (7, 3):
             b = im2.clone().requires_grad_(True)
             y = U.census_loss(im1, b, mask, ps)
@@ -444,7 +459,8 @@ def test_full_size_properties(AF):
     img = torch.rand(8, 3, 384, 640, device='cuda', generator=gen)
     z = torch.zeros(8, 2, 384, 640, device='cuda')
     # not exact in the reference either: x -> 2x/(W-1)-1 -> ((g+1)/2)(W-1) costs ~ulp(W) = 7.6e-5 at W=640
-    assert_close(AF.warp(img, z, 'zeros', True, AF.NORM_UFLOW), img, 3e-4, 0, 'identity warp')
+    # bound: (2 ulp(640) in x + 2 ulp(384) in y = 1.8e-4 px) x (image slope <= 1 per px for U[0,1) noise)
+    assert_close(AF.warp(img, z, 'zeros', True, AF.NORM_UFLOW), img, 2e-4, 0, 'identity warp')
     # census(a, a) = 0.01^0.4 on the valid interior
     from arflow_amd import uflow_utils as U
     ones = torch.ones(8, 1, 384, 640, device='cuda')
