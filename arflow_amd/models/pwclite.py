@@ -63,36 +63,40 @@ class PWCLite(nn.Module):
         return flows[::-1]
 
     def forward_3_frames(self, x0_pyramid, x1_pyramid, x2_pyramid):
-        """models/pwclite.py:206-258 (multi-view: two warps + two correlations per level)."""
+        """Multi-view pass of models/pwclite.py:206-258: the centre frame is matched against BOTH neighbours and
+        each view's decoder also sees the other view's cost volume and (negated) flow.
+
+        Here the two views (centre->0, centre->2) are stacked on the batch axis, like the two directions of the
+        2-frame pass: one warp, one cost volume, one estimator pass and one context pass per level at batch 2B
+        instead of two of each at batch B.  "The other view" of a stacked tensor is its two halves swapped.
+        Returns (flows centre->0, flows centre->2), finest first."""
+        B = x1_pyramid[0].shape[0]
+
+        def other(t):  # [view a; view b] -> [view b; view a]
+            return torch.cat([t[B:], t[:B]], 0)
+
         flows = []
-        b, _, h, w = x1_pyramid[0].shape
-        flow = torch.zeros(b, 4, h, w, dtype=torch.float32, device=x1_pyramid[0].device)
+        flow = None  # [2B,2,h,w]: rows 0..B-1 view (1->0), rows B..2B-1 view (1->2)
         for l, (x0, x1, x2) in enumerate(zip(x0_pyramid, x1_pyramid, x2_pyramid)):
-            if l == 0:
-                x0_warp, x2_warp = x0, x2
+            centre = torch.cat([x1, x1], 0)
+            neighbours = torch.cat([x0, x2], 0)
+            if flow is None:
+                flow = torch.zeros(2 * B, 2, *x1.shape[2:], dtype=torch.float32, device=x1.device)
             else:
                 flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
-                x0_warp = flow_warp(x0, flow[:, :2])
-                x2_warp = flow_warp(x2, flow[:, 2:])
-            corr_relu_10 = self.corr(x1, x0_warp, negative_slope=0.1)
-            corr_relu_12 = self.corr(x1, x2_warp, negative_slope=0.1)
-            x1_1by1 = self.conv_1x1[l](x1)
-            feat_10 = [x1_1by1, corr_relu_10, corr_relu_12, flow[:, :2], -flow[:, 2:]]
-            feat_12 = [x1_1by1, corr_relu_12, corr_relu_10, flow[:, 2:], -flow[:, :2]]
-            x_intm_10, flow_res_10 = self.flow_estimators(torch.cat(feat_10, dim=1))
-            x_intm_12, flow_res_12 = self.flow_estimators(torch.cat(feat_12, dim=1))
-            flow = flow + torch.cat([flow_res_10, flow_res_12], dim=1)
-            feat_10 = [x_intm_10, x_intm_12, flow[:, :2], -flow[:, 2:]]
-            feat_12 = [x_intm_12, x_intm_10, flow[:, 2:], -flow[:, :2]]
-            flow_res_10 = self.context_networks(torch.cat(feat_10, dim=1))
-            flow_res_12 = self.context_networks(torch.cat(feat_12, dim=1))
-            flow = flow + torch.cat([flow_res_10, flow_res_12], dim=1)
+                neighbours = flow_warp(neighbours, flow)
+            cost = self.corr(centre, neighbours, negative_slope=0.1)
+            squeezed = self.conv_1x1[l](x1)
+            feat, residual = self.flow_estimators(
+                torch.cat([torch.cat([squeezed, squeezed], 0), cost, other(cost), flow, -other(flow)], 1))
+            flow = flow + residual
+            flow = flow + self.context_networks(torch.cat([feat, other(feat), flow, -other(flow)], 1))
             flows.append(flow)
             if l == self.output_level:
                 break
         if self.upsample:
             flows = [F.interpolate(f * 4, scale_factor=4, mode='bilinear', align_corners=True) for f in flows]
-        return [f[:, :2] for f in flows[::-1]], [f[:, 2:] for f in flows[::-1]]
+        return [f[:B] for f in flows[::-1]], [f[B:] for f in flows[::-1]]
 
     def forward(self, x, with_bk=False):
         """models/pwclite.py:260-283 -> {'flows_fw': [...], 'flows_bw': [...]} finest first."""
@@ -115,12 +119,14 @@ class PWCLite(nn.Module):
             flows_10, flows_12 = self.forward_3_frames(pyrs[0], pyrs[1], pyrs[2])
             res['flows_fw'], res['flows_bw'] = flows_12, flows_10
         elif n_frames == 5:
-            flows_10, flows_12 = self.forward_3_frames(pyrs[0], pyrs[1], pyrs[2])
-            flows_21, flows_23 = self.forward_3_frames(pyrs[1], pyrs[2], pyrs[3])
-            res['flows_fw'] = [flows_12, flows_23]
+            # sliding multi-view windows (models/pwclite.py:274-281): window k is frames (k-1, k, k+1) around
+            # centre k; forward flows come from the windows centred on 1 and 2, backward ones on 2 and 3
+            def window(k):
+                return self.forward_3_frames(pyrs[k - 1], pyrs[k], pyrs[k + 1])  # (k -> k-1, k -> k+1)
+            w1, w2 = window(1), window(2)
+            res['flows_fw'] = [w1[1], w2[1]]
             if with_bk:
-                flows_32, flows_34 = self.forward_3_frames(pyrs[2], pyrs[3], pyrs[4])
-                res['flows_bw'] = [flows_21, flows_32]
+                res['flows_bw'] = [w2[0], window(3)[0]]
         else:
             raise NotImplementedError
         return res
