@@ -33,6 +33,10 @@ PROTOTYPES = {
     'arflow_occ_bidir': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_l, c_l, c_f, c_f, c_fp],
     'arflow_census_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'arflow_census_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_census_warp_supported': [c_i, c_i],
+    'arflow_census_warp_fwd': [c_fp, c_fp, c_fp, c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_census_warp_bwd': [c_fp, c_fp, c_fp, c_l, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_down4_gray': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'arflow_photo_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'arflow_photo_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'arflow_smooth_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_l, c_f, c_f, c_i, c_i, c_i, c_fp],

@@ -380,6 +380,74 @@ class CensusLossFunction(torch.autograd.Function):
         return ga, gb, None, None
 
 
+class CensusWarpLossFunction(torch.autograd.Function):
+    """One photometric direction of UFlowLoss (losses/uflow_loss.py:30-54) as ONE launch each way:
+    census_loss(im_a, resample(im_b, flow_to_warp(flow)), upsample(clamp(occ_small,0,1), x4) * mask_invalid(...)),
+    on the grey planes (x255) of the two images (``gray255``).  Returns (loss, mask).  Gradient w.r.t. the flow only
+    (the reference detaches the sampled image and the mask, losses/uflow_loss.py:31,34,43,48)."""
+
+    @staticmethod
+    def forward(ctx, gray_a, gray_b, flow, occ_small, patch_size):
+        _need_gpu(gray_a, gray_b, flow, occ_small)
+        gray_a, gray_b = gray_a.detach().contiguous(), gray_b.detach().contiguous()
+        flow, fbs = _flow_view(flow)
+        B, C, H, W = gray_a.shape
+        if C != 1 or gray_b.shape != gray_a.shape or flow.shape != (B, 2, H, W):
+            raise ValueError('census_warp_loss expects [B,1,H,W] grey planes and a [B,2,H,W] flow')
+        if occ_small is not None:
+            occ_small = occ_small.detach().contiguous()
+            if occ_small.shape != (B, 1, H // 4, W // 4):
+                raise ValueError('occ_small must be the [B,1,H/4,W/4] range map')
+        r = int(patch_size) // 2
+        buf = _new_sums(gray_a.device)
+        dham = torch.empty(B, 1, H, W, device=gray_a.device, dtype=torch.float32)
+        mask = torch.empty(B, 1, H, W, device=gray_a.device, dtype=torch.float32)
+        with torch.cuda.device_of(gray_a):
+            _call('arflow_census_warp_fwd', _p(gray_a), _p(gray_b), _p(flow), fbs, _p(occ_small), _p(mask), _p(dham),
+                  _p(buf), B, H, W, r, _stream(), key=(B, H, W))
+        sums = _fold_sums(buf, 2)
+        den = _ddp.global_denominator(sums[1]) + 1e-6 / _ddp.world_size()
+        inv = 1.0 / den
+        ctx.save_for_backward(gray_a, gray_b, flow, dham, inv)
+        ctx.r, ctx.fbs = r, fbs
+        ctx.mark_non_differentiable(mask)
+        return sums[0] * inv, mask
+
+    @staticmethod
+    def backward(ctx, gloss, gmask_unused):
+        gray_a, gray_b, flow, dham, inv = ctx.saved_tensors
+        B, _, H, W = gray_a.shape
+        scale = (gloss * inv).reshape(1).contiguous()
+        gflow = torch.empty(B, 2, H, W, device=gray_a.device, dtype=torch.float32)
+        with torch.cuda.device_of(gray_a):
+            _call('arflow_census_warp_bwd', _p(gray_a), _p(gray_b), _p(flow), ctx.fbs, _p(dham), _p(scale), _p(gflow),
+                  B, H, W, ctx.r, _stream(), key=(B, H, W))
+        return None, None, gflow, None, None
+
+
+def census_warp_supported(H, W):
+    return bool(_lib.load().arflow_census_warp_supported(int(H), int(W)))
+
+
+def census_warp_loss(gray_a, gray_b, flow, occ_small, patch_size=7):
+    return CensusWarpLossFunction.apply(gray_a, gray_b, flow, occ_small, patch_size)
+
+
+def down4_gray(img, want_small=True):
+    """(downsample(img, x1/4) or None, rgb_to_grayscale(img) * 255) from ONE read of the image (no gradient: the
+    reference applies both to data only, losses/uflow_loss.py:59-60, utils/uflow_utils.py:248)."""
+    _need_gpu(img)
+    img = img.detach().contiguous()
+    B, C, H, W = img.shape
+    if C != 3:
+        raise ValueError('down4_gray expects a [B,3,H,W] image')
+    small = torch.empty(B, 3, H // 4, W // 4, device=img.device, dtype=torch.float32) if want_small else None
+    gray = torch.empty(B, 1, H, W, device=img.device, dtype=torch.float32)
+    with torch.cuda.device_of(img):
+        _call('arflow_down4_gray', _p(img), _p(small), _p(gray), B, H, W, _stream(), key=(B, H, W))
+    return small, gray
+
+
 class TernaryDistFunction(torch.autograd.Function):
     """Per-pixel soft census distance (sum over the patch); TernaryLoss core,
     losses/loss_blocks.py:12-62."""

@@ -99,6 +99,15 @@ def algorithmic_bytes(name, shape):
     if name == 'arflow_census_bwd':
         B, H, W = shape
         return 4 * B * H * W * (3 + 3 + 1 + 3)
+    if name == 'arflow_census_warp_fwd':
+        B, H, W = shape[:3]  # grey a, grey b, flow 2, range map 1/16 in; mask 1, dham 1 out
+        return 4 * B * H * W * (1 + 1 + 2 + 1 + 1) + 4 * B * (H // 4) * (W // 4)
+    if name == 'arflow_census_warp_bwd':
+        B, H, W = shape[:3]  # grey a, grey b, flow 2, dham 1 in; gflow 2 out
+        return 4 * B * H * W * (1 + 1 + 2 + 1 + 2)
+    if name == 'arflow_down4_gray':
+        B, H, W = shape  # image 3 in; grey 1 + 3/16 out
+        return 4 * B * H * W * (3 + 1) + 4 * B * 3 * (H // 4) * (W // 4)
     if name == 'arflow_photo_fwd':
         B, C, H, W = shape
         return 4 * B * H * W * (2 * C + 1)

@@ -177,6 +177,36 @@ int arflow_census_fwd(const float* im_a, const float* im_b, const float* mask, f
 int arflow_census_bwd(const float* im_a, const float* im_b, const float* gham, const float* scale,
                       float* g_im_b, int B, int H, int W, int radius, arflow_stream_t stream);
 
+/* ---- fused photometric direction of UFlowLoss --------------------------------------------------------
+ * losses/uflow_loss.py:30-54 in one launch each way:
+ *     recons = resample(im_b, flow_to_warp(flow))                        (utils/uflow_utils.py:6-32,53-77)
+ *     mask   = upsample(clamp(occ_small,0,1), x4) * mask_invalid(flow_to_warp(flow))
+ *                                               (losses/uflow_loss.py:41-48, utils/uflow_utils.py:35-50,163-182)
+ *     sums   = census_loss numerator / denominator of (im_a, recons, mask)   (utils/uflow_utils.py:282-293)
+ * The census transform sees only rgb_to_grayscale(image) * 255 (utils/uflow_utils.py:227-231,248), and that is
+ * linear like the bilinear sample, so the kernels take the GREY planes gray_a, gray_b [B,1,H,W] (x255, from
+ * arflow_down4_gray) and sample one plane instead of three; the warped image, its gradient and the validity mask
+ * never exist in memory.  Equal to arflow_warp_fwd + arflow_up4_clamp_mul + arflow_census_fwd up to fp32
+ * re-association.
+ * flow: [B,2,H,W] with batch stride flow_bstride; occ_small: [B,1,H/4,W/4] (the range map of arflow_splat_map;
+ * NULL = no occlusion term, mask = validity only); mask_out: [B,1,H,W] or NULL; dham: [B,1,H,W] (saved for the
+ * backward); sums: as arflow_census_fwd (zero-filled here).
+ * Needs H % 4 == 0 and W % 4 == 0 (arflow_census_warp_supported() == 1), else ARFLOW_ESHAPE. */
+int arflow_census_warp_supported(int H, int W);
+int arflow_census_warp_fwd(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
+                           const float* occ_small, float* mask_out, float* dham, float* sums, int B, int H, int W,
+                           int radius, arflow_stream_t stream);
+/* gflow[B,2,H,W] = scale[0] * d(sums[0]) / d flow through the census distance and the bilinear sample
+ * (= arflow_census_bwd followed by arflow_warp_bwd with gsrc = NULL).  scale: device scalar or NULL (= 1). */
+int arflow_census_warp_bwd(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
+                           const float* dham, const float* scale, float* gflow, int B, int H, int W, int radius,
+                           arflow_stream_t stream);
+/* gray[B,1,H,W] = rgb_to_grayscale(im) * 255 (utils/uflow_utils.py:227-231) and, if small != NULL,
+ * small[B,3,H/4,W/4] = downsample(im, x1/4) as arflow_down4 (losses/uflow_loss.py:59-60) from the same read.
+ * im: [B,3,H,W], H % 4 == 0, W % 4 == 0. */
+int arflow_down4_gray(const float* im, float* small, float* gray, int B, int H, int W, arflow_stream_t stream);
+
+
 /* ---- SSIM + L1 photometric term (losses/flow_loss.py:13-27, losses/loss_blocks.py:65-84) --------
  * x = recons*mask, y = im*mask, 3x3 un-padded box SSIM, dist = clamp((1-SSIM)/2,0,1).
  * sums[0] += sum |im-recons|*mask  (B*C*H*W terms)

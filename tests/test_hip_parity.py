@@ -587,3 +587,49 @@ def test_random_shapes_fuzz(AF, oracle):
             gsr, = torch.autograd.grad(sr, fl)
             gsc, = torch.autograd.grad(sc_, flc)
             assert_close(gsc, gsr, 1e-6 + 1e-5 * float(gsr.abs().max()), 1e-4, tag + ' smooth grad')
+
+
+@pytest.mark.parametrize('size', [(2, 48, 64), (1, 16, 64), (3, 40, 132), (2, 96, 160)], ids=lambda s: 'x'.join(map(str, s)))
+def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size):
+    """arflow_census_warp_fwd/bwd (warp + validity + x4 mask upsample + census loss in one launch each way, on the
+    grey planes of arflow_down4_gray) against the three separate launches it replaces and against the oracle's
+    composition of the reference functions (losses/uflow_loss.py:30-54): mask bit-identical, loss and flow
+    gradient at the census tolerances (grey-then-sample re-associates fp32 sums)."""
+    from arflow_amd import uflow_utils as U
+    B, H, W = size
+    gen = torch.Generator().manual_seed(H + W)
+    im1, im2 = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, 3, H, W, generator=gen)
+    flow = 4.0 * torch.randn(B, 2, H, W, generator=gen)
+    flow[:, :, :2] += 30.0  # some samples leave the image: validity mask, zero padding
+    occ = 1.6 * torch.rand(B, 1, H // 4, W // 4, generator=gen) - 0.2  # exercises the clamp on both sides
+    # grey planes + x1/4 copies
+    small1, gray1 = AF.down4_gray(cu(im1))
+    _, gray2 = AF.down4_gray(cu(im2), want_small=False)
+    assert torch.equal(small1, AF.down4(cu(im1)))
+    assert_close(gray1, oracle.rgb_to_grayscale(im1) * 255, 0, 0, 'grey plane')
+    # unfused product path
+    f1 = cu(flow).requires_grad_(True)
+    rec, valid = AF.warp_with_valid(cu(im2), f1, pad='zeros', align_corners=True, norm=AF.NORM_UFLOW)
+    mask1 = AF.up4_clamp_mul(cu(occ), valid)
+    l1 = U.census_loss(cu(im1), rec, mask1)
+    g1, = torch.autograd.grad(l1, [f1])
+    # fused
+    f2 = cu(flow).requires_grad_(True)
+    l2, mask2 = AF.census_warp_loss(gray1, gray2, f2, cu(occ), 7)
+    g2, = torch.autograd.grad(l2, [f2])
+    assert torch.equal(mask1, mask2), 'mask differs from the unfused path'
+    assert_close(l2, l1, 1e-6, 1e-5, 'loss vs the unfused path')
+    assert_close(g2, g1, 1e-6 + 1e-4 * float(g1.abs().max()), 1e-3, 'flow gradient vs the unfused path')
+    # oracle
+    fr = flow.clone().requires_grad_(True)
+    coords = oracle.flow_to_warp(fr)
+    rmask = torch.nn.functional.interpolate(occ.clamp(0, 1), scale_factor=4, mode='bilinear', align_corners=False) * \
+        oracle.mask_invalid(coords)
+    lr = oracle.census_loss(im1, oracle.resample(im2, coords), rmask.detach())
+    gr, = torch.autograd.grad(lr, [fr])
+    assert_close(mask2, rmask, 1e-6, 1e-6, 'mask vs oracle')
+    assert_close(l2, lr, 1e-6, 1e-5, 'loss vs oracle')
+    assert_close(g2, gr, 1e-6 + 1e-4 * float(gr.abs().max()), 1e-3, 'flow gradient vs oracle')
+    # without the occlusion term (occ_small = NULL): mask = validity only
+    l3, mask3 = AF.census_warp_loss(gray1, gray2, cu(flow), None, 7)
+    assert torch.equal(mask3, valid)

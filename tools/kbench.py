@@ -115,6 +115,18 @@ def main():
         rec('arflow_census_fwd', (B, H0, W0), timeit(lambda: lib.arflow_census_fwd(p(im1), p(im2), p(mask), None, p(dham), p(sums), B, H0, W0, 3, s), args.iters))
     if want('census_bwd'):
         rec('arflow_census_bwd', (B, H0, W0), timeit(lambda: lib.arflow_census_bwd(p(im1), p(im2), p(dham), p(one), p(rec3), B, H0, W0, 3, s), args.iters))
+    if want('census_warp'):
+        occ = torch.rand(B, 1, H0 // 4, W0 // 4, device=dev, generator=g) * 1.5
+        maskw = torch.empty(B, 1, H0, W0, device=dev)
+        gr1, gr2 = torch.empty(B, 1, H0, W0, device=dev), torch.empty(B, 1, H0, W0, device=dev)
+        rec('arflow_down4_gray', (B, H0, W0), timeit(lambda: lib.arflow_down4_gray(p(im1), p(sm), p(gr1), B, H0, W0, s), args.iters))
+        lib.arflow_down4_gray(p(im2), None, p(gr2), B, H0, W0, s)
+        # a smooth flow (x4 bilinear upsample of a 2 px field, what the models emit) next to the white-noise one
+        fls = torch.nn.functional.interpolate(fl2 * 2, scale_factor=4, mode='bilinear', align_corners=False).contiguous()
+        rec('arflow_census_warp_fwd', (B, H0, W0, 'smooth'), timeit(lambda: lib.arflow_census_warp_fwd(p(gr1), p(gr2), p(fls), 2 * H0 * W0, p(occ), p(maskw), p(dham), p(sums), B, H0, W0, 3, s), args.iters))
+        rec('arflow_census_warp_bwd', (B, H0, W0, 'smooth'), timeit(lambda: lib.arflow_census_warp_bwd(p(gr1), p(gr2), p(fls), 2 * H0 * W0, p(dham), p(one), p(gfl0), B, H0, W0, 3, s), args.iters))
+        rec('arflow_census_warp_fwd', (B, H0, W0), timeit(lambda: lib.arflow_census_warp_fwd(p(gr1), p(gr2), p(fl0), 2 * H0 * W0, p(occ), p(maskw), p(dham), p(sums), B, H0, W0, 3, s), args.iters))
+        rec('arflow_census_warp_bwd', (B, H0, W0), timeit(lambda: lib.arflow_census_warp_bwd(p(gr1), p(gr2), p(fl0), 2 * H0 * W0, p(dham), p(one), p(gfl0), B, H0, W0, 3, s), args.iters))
     if want('photo_fwd'):
         rec('arflow_photo_fwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_photo_fwd(p(im1), p(im2), p(mask), None, p(sums), B, 3, H0, W0, s), args.iters))
     if want('photo_bwd'):
