@@ -21,6 +21,8 @@
 // The census arithmetic (census4 of photo.hip: 16 x 64 pixel tile, 4 pixels per lane, window rows as
 // ds_read_b128) is transcendental/VALU-bound; the ~6 extra dword gathers per pixel of the fill stage (tile + 3 px
 // halo = 1.5 x the tile, 4 taps each) are served by L2 and overlap other workgroups' arithmetic.
+#include <cstdlib>
+
 #include "census_tile.hpp"
 #include "taps.hpp"
 
@@ -305,6 +307,19 @@ __global__ __launch_bounds__(256) void down4_gray_kernel(const float* __restrict
 }  // namespace census_warp
 }  // namespace
 
+// Pair-symmetric kernels (census_sym.hip): every unordered pixel pair evaluated once, the value handed to the other
+// end through LDS -- half the transcendentals.  Built, parity-green and MEASURED slower than the ordered-pair kernels
+// of this file at the BASELINE shape (8x384x640: forward 76 us vs 58 us, backward 89 us vs 69 us), so
+// they are opt-in: ARFLOW_CENSUS_SYM=1 selects them (tests run both, tools/kbench.py times both).
+int census_sym_fwd(const float* gray_a, const float* gray_b, const float* flow, long fbs, const float* occ_small,
+                   float* mask_out, float* dham, float* sums, int B, int H, int W, int radius, hipStream_t st);
+int census_sym_bwd(const float* gray_a, const float* gray_b, const float* flow, long fbs, const float* dham,
+                   const float* scale, float* gflow, int B, int H, int W, int radius, hipStream_t st);
+static bool use_sym() {
+  const char* e = getenv("ARFLOW_CENSUS_SYM");
+  return e && e[0] == '1';
+}
+
 extern "C" int arflow_census_warp_supported(int H, int W) { return (W % 4 == 0 && H % 4 == 0 && H >= 8 && W >= 8) ? 1 : 0; }
 
 extern "C" int arflow_down4_gray(const float* im, float* small, float* gray, int B, int H, int W, arflow_stream_t stream) {
@@ -333,6 +348,7 @@ extern "C" int arflow_census_warp_fwd(const float* gray_a, const float* gray_b, 
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
   if (e != hipSuccess) return af_hip_status(e);
+  if (use_sym()) return census_sym_fwd(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, B, H, W, radius, st);
   namespace cw = census_warp;
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B));
   switch (radius) {
@@ -357,6 +373,7 @@ extern "C" int arflow_census_warp_bwd(const float* gray_a, const float* gray_b, 
   AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
   AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
+  if (use_sym()) return census_sym_bwd(gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, radius, st);
   namespace cw = census_warp;
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B));
   switch (radius) {

@@ -589,13 +589,16 @@ def test_random_shapes_fuzz(AF, oracle):
             assert_close(gsc, gsr, 1e-6 + 1e-5 * float(gsr.abs().max()), 1e-4, tag + ' smooth grad')
 
 
-@pytest.mark.parametrize('size', [(2, 48, 64), (1, 16, 64), (3, 40, 132), (2, 96, 160)], ids=lambda s: 'x'.join(map(str, s)))
-def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size):
+@pytest.mark.parametrize('sym', ['0', '1'], ids=['ordered', 'pair-symmetric'])
+@pytest.mark.parametrize('size', [(2, 48, 64), (1, 16, 64), (3, 40, 132), (2, 96, 160), (1, 100, 236)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, sym, monkeypatch):
     """arflow_census_warp_fwd/bwd (warp + validity + x4 mask upsample + census loss in one launch each way, on the
     grey planes of arflow_down4_gray) against the three separate launches it replaces and against the oracle's
     composition of the reference functions (losses/uflow_loss.py:30-54): mask bit-identical, loss and flow
     gradient at the census tolerances (grey-then-sample re-associates fp32 sums)."""
     from arflow_amd import uflow_utils as U
+    monkeypatch.setenv('ARFLOW_CENSUS_SYM', sym)  # read by the library at every call: both kernel families are tested
     B, H, W = size
     gen = torch.Generator().manual_seed(H + W)
     im1, im2 = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, 3, H, W, generator=gen)
