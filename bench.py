@@ -132,15 +132,47 @@ def algorithmic_bytes(name, shape):
     return 0
 
 
-def pmc_traffic(name, shape):
-    """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs of tools/kbench.py on the same shapes, gfx950 correction applied by
-    tools/make_traffic.py), or None when that launch shape was not profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
-    table = json.load(open(path))
+# Measured VALU ceilings of one MI355X (tools/ubench/valu_rate.hip, profiles/r02_valu_rate.log): v_fma_f32 issues
+# 55.4 T lane-instructions/s chip-wide (2.84 cycles per wave-instruction per SIMD), v_rsq_f32 / v_rcp_f32 19.2 T/s.
+# A kernel's algorithmic VALU work is priced in "v_fma slots": 1 per plain fp32 op, TRANS_SLOTS per transcendental.
+VALU_PEAK_TSLOTS = 55.4
+TRANS_SLOTS = 55.4 / 19.2
 
+
+def valu_slots(name, shape):
+    """Algorithmic VALU work of one launch in v_fma-equivalent lane slots (arithmetic the algorithm needs, not the
+    instructions the kernel happens to issue): the counterpart of algorithmic_bytes() for the kernels the PMC pass
+    shows VALU-bound (profiles/r02_pmc_valu.json).  0 = not modelled (HBM side only)."""
+    T = TRANS_SLOTS
+    if name in ('arflow_census_fwd', 'arflow_census_warp_fwd'):
+        B, H, W = shape[:3]  # 49 neighbours x (2 sub, 2 fma, 2 rsq, mul, fma, mul, add, rcp, fma) per image pair
+        return B * H * W * 49 * (10 + 3 * T)
+    if name in ('arflow_census_bwd', 'arflow_census_warp_bwd'):
+        B, H, W = shape[:3]  # 48 neighbours x (2 sub, 2 fma, 2 rsq, mul, fma, fma, rcp, 5 mul, add, fma)
+        return B * H * W * 48 * (14 + 3 * T)
+    if name == 'arflow_photo_fwd':
+        B, C, H, W = shape  # per pixel-channel: 2 mask products, 3 products, 5 x 9-tap sums, SSIM closed form (1 rcp)
+        return B * C * H * W * (5 + 45 + 30 + T)
+    if name == 'arflow_photo_bwd':
+        B, C, H, W = shape  # window coefficients (as forward) + 9 windows x 3 fma per pixel
+        return B * C * H * W * (5 + 45 + 45 + 2 * T + 27)
+    if name == 'arflow_corr_fwd':
+        B, C, H, W, d = shape[:5]
+        return B * H * W * (2 * d + 1) ** 2 * C
+    if name == 'arflow_corr_bwd':
+        B, C, H, W, d = shape[:5]
+        return B * H * W * (2 * d + 1) ** 2 * C * 2
+    if name == 'arflow_warp_fwd':
+        B, C, H, W = shape  # coordinates + taps ~60, 4 fma per channel
+        return B * H * W * (60 + 4 * C)
+    if name == 'arflow_warp_bwd':
+        B, C, H, W, with_src = shape  # flow gradient: 8 per channel; source gradient: 4 per channel
+        return B * H * W * (70 + (12 if with_src else 8) * C)
+    return 0
+
+
+def kernel_keys(name, shape):
+    """(kernel symbol | grid threads) keys under which the PMC passes over tools/kbench.py filed this launch."""
     def cdiv(a, b):
         return (a + b - 1) // b
 
@@ -160,6 +192,12 @@ def pmc_traffic(name, shape):
     if name in ('arflow_census_fwd', 'arflow_census_bwd'):
         B, H, W = shape
         keys = ['census4::%s_kernel<3>|%d' % (name[-3:], grid(cdiv(W, 64) * cdiv(H, 16) * B, 256))]
+    elif name in ('arflow_census_warp_fwd', 'arflow_census_warp_bwd'):
+        B, H, W = shape[:3]
+        keys = ['census_warp::%s_kernel<3>|%d' % (name[-3:], grid(cdiv(W, 64) * cdiv(H, 16) * B, 256))]
+    elif name in ('arflow_photo_fwd', 'arflow_photo_bwd'):
+        B, C, H, W = shape
+        keys = ['photo4::%s_kernel|%d' % (name[-3:], grid(cdiv(W, 64) * cdiv(H, 16) * B, 256))]
     elif name == 'arflow_corr_fwd':
         B, C, H, W = shape[:4]
         tiles = cdiv(W, 32) * cdiv(H, 8) * B
@@ -186,9 +224,53 @@ def pmc_traffic(name, shape):
         B, n = shape
         k1, k2 = ('moment_kernel', 'apply_kernel') if name.endswith('fwd') else ('bwd_sum_kernel', 'bwd_apply_kernel')
         keys = ['%s|%d' % (k1, per_sample(B, n, 256 * 16) * B * 256), '%s|%d' % (k2, per_sample(B, n, 256 * 4) * B * 256)]
-    if not keys or any(k not in table for k in keys):
-        return None
-    return sum(table[k]['hbm_bytes'] for k in keys)
+    return keys
+
+
+def _pmc_table(fname):
+    path = os.path.join(ROOT, 'profiles', fname)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def pmc_traffic(name, shape):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
+    in separate runs of tools/kbench.py on the same shapes, gfx950 correction applied by tools/make_traffic.py), or
+    None when that launch shape was not profiled."""
+    keys = kernel_keys(name, shape)
+    for fname in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        table = _pmc_table(fname)
+        if table and keys and all(k in table for k in keys):
+            return sum(table[k]['hbm_bytes'] for k in keys)
+    return None
+
+
+def pmc_valu_busy(name, shape):
+    """Share of the chip's SIMD time the launch's dominant kernel spent issuing VALU instructions (PMC pass
+    profiles/r02_pmc_valu.json, tools/pmc_valu.py), or None."""
+    table = _pmc_table('r02_pmc_valu.json')
+    keys = kernel_keys(name, shape)
+    vals = [table[k]['valu_busy'] for k in keys if table and k in table and table[k].get('valu_busy') is not None]
+    return max(vals) if vals else None
+
+
+def roof(name, shape, avg_ms):
+    """Which roof bounds this launch and how close it runs to it: HBM time = algorithmic bytes / 8 TB/s, VALU time =
+    algorithmic slots / measured v_fma ceiling; the larger one is the bound.  `valu_busy_pmc` (share of the chip's SIMD
+    time spent issuing VALU instructions, from the PMC pass) is reported next to it: a kernel can sit under the HBM roof
+    of its ALGORITHM and still be limited by the instructions its implementation issues.  Returns the `roofline` object."""
+    nbytes, slots = algorithmic_bytes(name, shape), valu_slots(name, shape)
+    t = avg_ms * 1e-3
+    t_hbm, t_valu = nbytes / (HBM_PEAK_GBS * 1e9), slots / (VALU_PEAK_TSLOTS * 1e12)
+    busy = pmc_valu_busy(name, shape)
+    hbm = {'achieved': nbytes / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': t_hbm / t}
+    r = {'kernel': name, 'shape': list(shape), 'avg_us': 1e6 * t, 'algorithmic_bytes': nbytes,
+         'traffic': pmc_traffic(name, shape), 'valu_busy_pmc': busy}
+    if slots and t_valu > t_hbm:
+        r.update({'bound': 'valu', 'achieved': slots / t / 1e12, 'peak': VALU_PEAK_TSLOTS, 'unit': 'T v_fma-slots/s',
+                  'frac': t_valu / t, 'algorithmic_valu_slots': slots, 'hbm': hbm})
+    else:
+        r.update({'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm['frac']})
+    return r
 
 
 def cpu_baseline(workload, height, width, budget_s=25.0):
@@ -387,22 +469,30 @@ def main():
                                  'GBps': g_bytes / (g_ms * 1e-3) / 1e9, 'launches_per_step': sum(v[1] for v in glue.values()) / len(sampled)}
         if per:
             (name, shape), (tot, n) = max(per.items(), key=lambda kv: kv[1][0])
-            avg_ms = tot / n
-            nbytes = algorithmic_bytes(name, shape)
-            ach = nbytes / (avg_ms * 1e-3) / 1e9
-            line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic(name, shape), 'kernel': name, 'shape': list(shape),
-                                'avg_us': 1e3 * avg_ms, 'launches_per_step': n / len(sampled),
-                                'algorithmic_bytes': nbytes}
+            # the dominant hot-path kernel against the roof that bounds IT (HBM or VALU, see roof())
+            line['roofline'] = roof(name, shape, tot / n)
+            line['roofline']['launches_per_step'] = n / len(sampled)
             hot_ms = sum(v[0] for v in per.values()) / len(sampled)
             hot_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in per.items()) / len(sampled)
+            roofs = {k: roof(k[0], k[1], v[0] / v[1]) for k, v in per.items()}
+            # aggregate over the HBM-bound launches only (the VALU-bound ones are priced against the VALU ceiling),
+            # and the time the whole hot path would take with every launch AT its own roof
+            hb = [(k, v) for k, v in per.items() if roofs[k]['bound'] == 'hbm']
+            hb_ms = sum(v[0] for _, v in hb) / len(sampled)
+            hb_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in hb) / len(sampled)
+            at_roof_ms = sum(roofs[k]['frac'] * v[0] for k, v in per.items()) / len(sampled)
             line['hot_path'] = {'ms_per_step': hot_ms, 'algorithmic_GB_per_step': hot_bytes / 1e9,
                                 'GBps': hot_bytes / (hot_ms * 1e-3) / 1e9,
                                 'frac_of_hbm_peak': hot_bytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'hbm_bound_only': {'ms_per_step': hb_ms, 'algorithmic_GB_per_step': hb_bytes / 1e9,
+                                                   'frac_of_hbm_peak': (hb_bytes / (hb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hb_ms else None},
+                                'frac_of_own_roofs': at_roof_ms / hot_ms,
                                 'share_of_step': hot_ms / (1e3 * elapsed / args.steps),
                                 'kernels': {('%s%s' % (k[0], list(k[1]))): {'us': 1e3 * v[0] / v[1], 'n': v[1] / len(sampled),
-                                                                           'GBps': algorithmic_bytes(k[0], k[1]) / (v[0] / v[1] * 1e-3) / 1e9}
-                                            for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:12]}}
+                                                                           'GBps': algorithmic_bytes(k[0], k[1]) / (v[0] / v[1] * 1e-3) / 1e9,
+                                                                           'bound': roofs[k]['bound'], 'frac_of_roof': roofs[k]['frac'],
+                                                                           'valu_busy_pmc': roofs[k]['valu_busy_pmc']}
+                                            for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:14]}}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.workload, H, W)
