@@ -21,7 +21,14 @@ PROTOTYPES = {
     'arflow_take_stale_error': [],
     'arflow_corr_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_corr_sign_planes': [c_i, c_i, c_i],
+    'arflow_corr_strided_supported': [c_i, c_i, c_i],
+    'arflow_corr_fwd_strided': [c_fp, c_fp, c_fp, c_l, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'arflow_corr_bwd_strided': [c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_corr_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'arflow_corr_fwd_bf16': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'arflow_corr_bwd_bf16': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'arflow_warp_fwd_bf16': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_warp_bwd_bf16': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_featnorm_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
     'arflow_featnorm_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
     'arflow_bias_act_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_l, c_f, c_fp],
@@ -45,7 +52,7 @@ PROTOTYPES = {
     'arflow_up4_clamp_mul': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -11,8 +11,11 @@ from . import functional as AF
 
 class Correlation(nn.Module):
     def __init__(self, pad_size=None, kernel_size=1, max_displacement=4, stride1=1, stride2=1,
-                 corr_multiply=1, **kwargs):
+                 corr_multiply=1, storage_dtype=None, **kwargs):
+        """storage_dtype=torch.bfloat16 (opt-in, not in the reference's signature): keep the features as bf16 in
+        HBM -- fp32 accumulation, fp32 volume and gradients."""
         super().__init__()
+        self.storage = storage_dtype
         if pad_size is None:
             pad_size = max_displacement
         # models/correlation_native.py:7 swallows these arguments and always computes the
@@ -27,7 +30,25 @@ class Correlation(nn.Module):
     def forward(self, x1, x2, negative_slope=1.0):
         """``negative_slope`` != 1 fuses the LeakyReLU the callers apply to the volume
         (models/pwclite.py:183-184) into the kernel; the default is the reference's plain volume."""
-        return AF.correlation(x1, x2, self.max_displacement, negative_slope)
+        return AF.correlation(x1, x2, self.max_displacement, negative_slope, storage=self.storage)
+
+    def concat(self, x1, x2, before=(), after=(), negative_slope=1.0):
+        """torch.cat([*before, forward(x1, x2, negative_slope), *after], 1) -- what every decoder does with the volume
+        next (models/pwclite.py:187-189, models/pwclite_uflow.py:218-222) -- with the volume written by the kernel
+        straight into its channel slot of the concatenated tensor instead of being copied there."""
+        if self.storage is not None:
+            import torch
+            return torch.cat(list(before) + [self.forward(x1, x2, negative_slope)] + list(after), 1)
+        return AF.correlation_concat(x1, x2, before, after, self.max_displacement, negative_slope)
+
+
+def cost_volume_concat(features1, features2, before, after, max_displacement, negative_slope=1.0):
+    """torch.cat([*before, compute_cost_volume(...), *after], 1) without the copy of the volume
+    (models/uflow_model.py:175-198)."""
+    _, _, height, _ = features1.shape
+    if max_displacement <= 0 or max_displacement >= height:
+        raise ValueError(f'Max displacement of {max_displacement} is too large.')
+    return AF.correlation_concat(features1, features2, before, after, max_displacement, negative_slope)
 
 
 def compute_cost_volume(features1, features2, max_displacement, negative_slope=1.0):

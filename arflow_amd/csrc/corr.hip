@@ -23,12 +23,19 @@
 
 namespace {
 
+// Feature storage type of the tiled kernels below: float, or bf16 bit patterns (opt-in bf16
+// STORAGE of the correlation inputs -- the reference's native path dispatches half as well,
+// correlation_cuda_kernel.cu:352,369; arithmetic and outputs stay fp32).
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+
 // ------------------------------------------------------------------------------------------------
 // cooperative tile loader: CC channels of a (ROWS x COLS) window whose top-left pixel is (gy0,gx0),
 // zero outside the image / past the last channel.  dst layout [CC][ROWS][PITCH].
 // ------------------------------------------------------------------------------------------------
-template <int CC, int ROWS, int COLS, int PITCH, int NT>
-__device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* __restrict__ src,
+template <int CC, int ROWS, int COLS, int PITCH, int NT, typename TX>
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, const TX* __restrict__ src,
                                           int c0, int C, int H, int W, int gy0, int gx0) {
   constexpr int PER = ROWS * COLS;
   for (int idx = threadIdx.x; idx < CC * PER; idx += NT) {
@@ -39,7 +46,7 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, const float* 
     const int gy = gy0 + r, gx = gx0 + x;
     float v = 0.f;
     if (c0 + c < C && gy >= 0 && gy < H && gx >= 0 && gx < W)
-      v = src[((long)(c0 + c) * H + gy) * W + gx];
+      v = to_f32(src[((long)(c0 + c) * H + gy) * W + gx]);
     dst[(c * ROWS + r) * PITCH + x] = v;
   }
 }
@@ -59,10 +66,10 @@ struct FwdCfg {
   static constexpr int LDS_FLOATS = CC * (TH * TW + R2 * P2);
 };
 
-template <int D, int PX, int TW, int CC>
+template <int D, int PX, int TW, int CC, typename TX>
 // two workgroups (2N waves) per CU: ceil(2N/4) waves per SIMD bounds the VGPR budget
 __global__ __launch_bounds__(64 * (2 * D + 1), (2 * (2 * D + 1) + 3) / 4) void corr_fwd_kernel(
-    const float* __restrict__ x1, const float* __restrict__ x2, float* __restrict__ out, int C, int H,
+    const TX* __restrict__ x1, const TX* __restrict__ x2, float* __restrict__ out, int C, int H,
     int W, float inv_c, float slope) {
   using K = FwdCfg<D, PX, TW, CC>;
   constexpr int N = K::N, TH = K::TH, R2 = K::R2, P2 = K::P2;
@@ -73,8 +80,8 @@ __global__ __launch_bounds__(64 * (2 * D + 1), (2 * (2 * D + 1) + 3) / 4) void c
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ry = lane / K::LPR, sx = (lane % K::LPR) * PX;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH, b = blockIdx.z;
-  const float* x1b = x1 + (long)b * C * H * W;
-  const float* x2b = x2 + (long)b * C * H * W;
+  const TX* x1b = x1 + (long)b * C * H * W;
+  const TX* x2b = x2 + (long)b * C * H * W;
 
   float acc[N][PX];
 #pragma unroll
@@ -83,8 +90,8 @@ __global__ __launch_bounds__(64 * (2 * D + 1), (2 * (2 * D + 1) + 3) / 4) void c
     for (int p = 0; p < PX; ++p) acc[j][p] = 0.f;
 
   for (int c0 = 0; c0 < C; c0 += CC) {
-    load_tile<CC, TH, TW, TW, K::NT>(s1, x1b, c0, C, H, W, ty0, tx0);
-    load_tile<CC, R2, K::C2, P2, K::NT>(s2, x2b, c0, C, H, W, ty0 - D, tx0 - D);
+    load_tile<CC, TH, TW, TW, K::NT, TX>(s1, x1b, c0, C, H, W, ty0, tx0);
+    load_tile<CC, R2, K::C2, P2, K::NT, TX>(s2, x2b, c0, C, H, W, ty0 - D, tx0 - D);
     __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < CC; ++c) {
@@ -145,12 +152,12 @@ __global__ __launch_bounds__(64 * (2 * D + 1), (2 * (2 * D + 1) + 3) / 4) void c
   }
 }
 
-template <int D, int PX, int TW, int CC>
-int launch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, float slope,
+template <int D, int PX, int TW, int CC, typename TX>
+int launch_fwd(const TX* x1, const TX* x2, float* out, int B, int C, int H, int W, float slope,
                hipStream_t st) {
   using K = FwdCfg<D, PX, TW, CC>;
   dim3 grid(af_cdiv(W, TW), af_cdiv(H, K::TH), B);
-  hipLaunchKernelGGL((corr_fwd_kernel<D, PX, TW, CC>), grid, dim3(K::NT), 0, st, x1, x2, out, C, H, W,
+  hipLaunchKernelGGL((corr_fwd_kernel<D, PX, TW, CC, TX>), grid, dim3(K::NT), 0, st, x1, x2, out, C, H, W,
                      1.0f / (float)C, slope);
   return af_launch_status();
 }
@@ -169,11 +176,11 @@ struct BwdCfg {
   static constexpr int LDS_FLOATS = CC * R2 * P2;
 };
 
-template <int D, int PX, int TW, int CC, int NT>
+template <int D, int PX, int TW, int CC, int NT, typename TX>
 __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict__ gout,
                                                      const float* __restrict__ fout, float slope,
-                                                     const float* __restrict__ x1,
-                                                     const float* __restrict__ x2,
+                                                     const TX* __restrict__ x1,
+                                                     const TX* __restrict__ x2,
                                                      float* __restrict__ gx1, float* __restrict__ gx2,
                                                      int B, int C, int H, int W, float inv_c,
                                                      int mode_base) {
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict
   const int ry = threadIdx.x / K::LPR, sx = (threadIdx.x % K::LPR) * PX;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * K::TH;
   const int gy = ty0 + ry, gx = tx0 + sx;
-  const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * H * W;
+  const TX* srcb = (mode == 0 ? x2 : x1) + (long)b * C * H * W;
   float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * H * W;
   const float* gb = gout + (long)b * N * N * H * W;
   const float* fb = fout ? fout + (long)b * N * N * H * W : nullptr;
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict
 
   for (int c0 = 0; c0 < C; c0 += CC) {
     __syncthreads();
-    load_tile<CC, R2, K::C2, P2, NT>(s2, srcb, c0, C, H, W, ty0 - D, tx0 - D);
+    load_tile<CC, R2, K::C2, P2, NT, TX>(s2, srcb, c0, C, H, W, ty0 - D, tx0 - D);
     __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < CC; ++c) {
@@ -255,14 +262,14 @@ __global__ __launch_bounds__(NT, 2) void corr_bwd_kernel(const float* __restrict
   }
 }
 
-template <int D, int PX, int TW, int CC, int NT>
-int launch_bwd(const float* gout, const float* fout, float slope, const float* x1, const float* x2, float* gx1,
+template <int D, int PX, int TW, int CC, int NT, typename TX>
+int launch_bwd(const float* gout, const float* fout, float slope, const TX* x1, const TX* x2, float* gx1,
                float* gx2, int B, int C, int H, int W, hipStream_t st) {
   using K = BwdCfg<D, PX, TW, CC, NT>;
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
   dim3 grid(af_cdiv(W, TW), af_cdiv(H, K::TH), B * nmodes);
-  hipLaunchKernelGGL((corr_bwd_kernel<D, PX, TW, CC, NT>), grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B,
+  hipLaunchKernelGGL((corr_bwd_kernel<D, PX, TW, CC, NT, TX>), grid, dim3(NT), 0, st, gout, fout, slope, x1, x2, gx1, gx2, B,
                      C, H, W, 1.0f / (float)C, gx1 ? 0 : 1);
   return af_launch_status();
 }
@@ -326,23 +333,23 @@ __global__ void corr_bwd_generic(const float* __restrict__ gout, const float* __
   }
 }
 
-template <int D>
-int dispatch_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, float slope,
+template <int D, typename TX>
+int dispatch_fwd(const TX* x1, const TX* x2, float* out, int B, int C, int H, int W, float slope,
                  hipStream_t st) {
   // pick the widest lane strip that still yields enough workgroups to occupy the chip
   const long px = (long)B * H * W;
-  if (W >= 24 && px >= 32768) return launch_fwd<D, 8, 32, 8>(x1, x2, out, B, C, H, W, slope, st);
-  if (W >= 12 && px >= 8192) return launch_fwd<D, 4, 16, 8>(x1, x2, out, B, C, H, W, slope, st);
-  return launch_fwd<D, 2, 16, 8>(x1, x2, out, B, C, H, W, slope, st);
+  if (W >= 24 && px >= 32768) return launch_fwd<D, 8, 32, 8, TX>(x1, x2, out, B, C, H, W, slope, st);
+  if (W >= 12 && px >= 8192) return launch_fwd<D, 4, 16, 8, TX>(x1, x2, out, B, C, H, W, slope, st);
+  return launch_fwd<D, 2, 16, 8, TX>(x1, x2, out, B, C, H, W, slope, st);
 }
 
-template <int D>
-int dispatch_bwd(const float* gout, const float* fout, float slope, const float* x1, const float* x2, float* gx1,
+template <int D, typename TX>
+int dispatch_bwd(const float* gout, const float* fout, float slope, const TX* x1, const TX* x2, float* gx1,
                  float* gx2, int B, int C, int H, int W, hipStream_t st) {
   const long px = (long)B * H * W;
-  if (W >= 48 && px >= 65536) return launch_bwd<D, 2, 64, 8, 256>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
-  if (W >= 24 && px >= 8192) return launch_bwd<D, 2, 32, 8, 128>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
-  return launch_bwd<D, 1, 16, 8, 64>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+  if (W >= 48 && px >= 65536) return launch_bwd<D, 2, 64, 8, 256, TX>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+  if (W >= 24 && px >= 8192) return launch_bwd<D, 2, 32, 8, 128, TX>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+  return launch_bwd<D, 1, 16, 8, 64, TX>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
 }
 
 }  // namespace
@@ -351,8 +358,22 @@ extern "C" int arflow_corr_sign_planes(int C, int W, int max_disp) {
   return corr_v2::eligible(C, W, max_disp) ? corr_v2::NW : 0;
 }
 
+static int corr_fwd_impl(const float* x1, const float* x2, float* out, long out_bstride, unsigned* sign_bits, int B,
+                         int C, int H, int W, int max_disp, float negative_slope, arflow_stream_t stream);
 extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C,
                                int H, int W, int max_disp, float negative_slope, arflow_stream_t stream) {
+  return corr_fwd_impl(x1, x2, out, 0, sign_bits, B, C, H, W, max_disp, negative_slope, stream);
+}
+extern "C" int arflow_corr_strided_supported(int C, int W, int max_disp) { return corr_v2::eligible(C, W, max_disp) ? 1 : 0; }
+extern "C" int arflow_corr_fwd_strided(const float* x1, const float* x2, float* out, long out_bstride,
+                                       unsigned* sign_bits, int B, int C, int H, int W, int max_disp,
+                                       float negative_slope, arflow_stream_t stream) {
+  AF_REQUIRE(corr_v2::eligible(C, W, max_disp), ARFLOW_EPARAM);
+  AF_REQUIRE(out_bstride >= (long)(2 * max_disp + 1) * (2 * max_disp + 1) * H * W && out_bstride % 4 == 0, ARFLOW_ESHAPE);
+  return corr_fwd_impl(x1, x2, out, out_bstride, sign_bits, B, C, H, W, max_disp, negative_slope, stream);
+}
+static int corr_fwd_impl(const float* x1, const float* x2, float* out, long out_bstride, unsigned* sign_bits, int B,
+                         int C, int H, int W, int max_disp, float negative_slope, arflow_stream_t stream) {
   af_clear_stale_error();
   const float slope = negative_slope;
   AF_REQUIRE_PTR(x1);
@@ -362,13 +383,13 @@ extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, uns
   AF_REQUIRE(max_disp >= 1, ARFLOW_EPARAM);
   AF_REQUIRE(B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  if (corr_v2::eligible(C, W, max_disp)) return corr_v2::launch_fwd(x1, x2, out, sign_bits, B, C, H, W, slope, st);
+  if (corr_v2::eligible(C, W, max_disp)) return corr_v2::launch_fwd(x1, x2, out, sign_bits, B, C, H, W, slope, st, out_bstride);
   AF_REQUIRE(sign_bits == nullptr, ARFLOW_EPARAM);  // only the fast path records signs
   switch (max_disp) {
-    case 1: return dispatch_fwd<1>(x1, x2, out, B, C, H, W, slope, st);
-    case 2: return dispatch_fwd<2>(x1, x2, out, B, C, H, W, slope, st);
-    case 3: return dispatch_fwd<3>(x1, x2, out, B, C, H, W, slope, st);
-    case 4: return dispatch_fwd<4>(x1, x2, out, B, C, H, W, slope, st);
+    case 1: return dispatch_fwd<1, float>(x1, x2, out, B, C, H, W, slope, st);
+    case 2: return dispatch_fwd<2, float>(x1, x2, out, B, C, H, W, slope, st);
+    case 3: return dispatch_fwd<3, float>(x1, x2, out, B, C, H, W, slope, st);
+    case 4: return dispatch_fwd<4, float>(x1, x2, out, B, C, H, W, slope, st);
     default: {
       const int N = 2 * max_disp + 1;
       const long total = (long)B * N * N * H * W;
@@ -379,9 +400,28 @@ extern "C" int arflow_corr_fwd(const float* x1, const float* x2, float* out, uns
   }
 }
 
+static int corr_bwd_impl(const float* gout, long gout_bstride, const float* out, long out_bstride,
+                         const unsigned* sign_bits, const float* x1, const float* x2, float* gx1, float* gx2, int B, int C,
+                         int H, int W, int max_disp, float negative_slope, arflow_stream_t stream);
 extern "C" int arflow_corr_bwd(const float* gout, const float* out, const unsigned* sign_bits, const float* x1,
                                const float* x2, float* gx1, float* gx2, int B, int C, int H, int W, int max_disp,
                                float negative_slope, arflow_stream_t stream) {
+  return corr_bwd_impl(gout, 0, out, 0, sign_bits, x1, x2, gx1, gx2, B, C, H, W, max_disp, negative_slope, stream);
+}
+extern "C" int arflow_corr_bwd_strided(const float* gout, long gout_bstride, const float* out, long out_bstride,
+                                       const unsigned* sign_bits, const float* x1, const float* x2, float* gx1,
+                                       float* gx2, int B, int C, int H, int W, int max_disp, float negative_slope,
+                                       arflow_stream_t stream) {
+  AF_REQUIRE(corr_v2::eligible(C, W, max_disp), ARFLOW_EPARAM);
+  const long vol = (long)(2 * max_disp + 1) * (2 * max_disp + 1) * H * W;
+  AF_REQUIRE(gout_bstride >= vol && gout_bstride % 4 == 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(out == nullptr || (out_bstride >= vol && out_bstride % 4 == 0), ARFLOW_ESHAPE);
+  return corr_bwd_impl(gout, gout_bstride, out, out_bstride, sign_bits, x1, x2, gx1, gx2, B, C, H, W, max_disp,
+                       negative_slope, stream);
+}
+static int corr_bwd_impl(const float* gout, long gout_bstride, const float* out, long out_bstride,
+                         const unsigned* sign_bits, const float* x1, const float* x2, float* gx1, float* gx2, int B, int C,
+                         int H, int W, int max_disp, float negative_slope, arflow_stream_t stream) {
   af_clear_stale_error();
   AF_REQUIRE_PTR(gout);
   const float slope = negative_slope;
@@ -399,12 +439,12 @@ extern "C" int arflow_corr_bwd(const float* gout, const float* out, const unsign
   AF_REQUIRE(max_disp >= 1, ARFLOW_EPARAM);
   AF_REQUIRE(2 * B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  if (fast) return corr_v2::launch_bwd(gout, fout, sign_bits, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+  if (fast) return corr_v2::launch_bwd(gout, fout, sign_bits, slope, x1, x2, gx1, gx2, B, C, H, W, st, gout_bstride, out_bstride);
   switch (max_disp) {
-    case 1: return dispatch_bwd<1>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
-    case 2: return dispatch_bwd<2>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
-    case 3: return dispatch_bwd<3>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
-    case 4: return dispatch_bwd<4>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 1: return dispatch_bwd<1, float>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 2: return dispatch_bwd<2, float>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 3: return dispatch_bwd<3, float>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
+    case 4: return dispatch_bwd<4, float>(gout, fout, slope, x1, x2, gx1, gx2, B, C, H, W, st);
     default: {
       const long total = (long)B * C * H * W;
       hipLaunchKernelGGL(corr_bwd_generic, dim3((unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256)),
@@ -412,4 +452,35 @@ extern "C" int arflow_corr_bwd(const float* gout, const float* out, const unsign
       return af_launch_status();
     }
   }
+}
+
+// ---- bf16 STORAGE of the features (opt-in): x1, x2 hold bf16 bit patterns, the products are
+// accumulated in fp32, the volume and both gradients are fp32.  The LDS-tiled kernels above with a converting loader.
+extern "C" int arflow_corr_fwd_bf16(const unsigned short* x1, const unsigned short* x2, float* out, int B, int C, int H,
+                                    int W, int max_disp, float negative_slope, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(max_disp == 4, ARFLOW_EPARAM);  // the only displacement the reference's models use
+  return dispatch_fwd<4, bf16_t>(x1, x2, out, B, C, H, W, negative_slope, (hipStream_t)stream);
+}
+
+extern "C" int arflow_corr_bwd_bf16(const float* gout, const float* out, const unsigned short* x1,
+                                    const unsigned short* x2, float* gx1, float* gx2, int B, int C, int H, int W,
+                                    int max_disp, float negative_slope, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gout);
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && 2 * B <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(max_disp == 4, ARFLOW_EPARAM);
+  const bool act = negative_slope != 1.0f;
+  if (act) {
+    AF_REQUIRE_PTR(out);  // LeakyReLU derivative from the sign of the forward output
+    AF_REQUIRE(negative_slope >= 0.f, ARFLOW_EPARAM);
+  }
+  return dispatch_bwd<4, bf16_t>(gout, act ? out : nullptr, negative_slope, x1, x2, gx1, gx2, B, C, H, W,
+                                 (hipStream_t)stream);
 }

@@ -111,9 +111,12 @@ inline unsigned grid_for_tiles(int T) { return 8u * (unsigned)((T + 7) / 8); }
 // (float atomics into the volume were 6x slower than no split at all).  Needs (C / 4) % G == 0; one such
 // workgroup (G = 4: 12 waves, 124 KB of LDS) fills a CU.
 template <int NBUF, int G>
-__global__ __launch_bounds__(NT * G, 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+// (the 4-buffer ring of the few-tiles form needs 2 waves/SIMD worth of registers: asking for 3 only earned a
+// "failed to meet occupancy target" remark)
+__global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                         float* __restrict__ out, unsigned* __restrict__ sign_bits,
-                                                        int nimg, int C, int H, int W, float inv_c, float slope) {
+                                                        int nimg, int C, int H, int W, float inv_c, float slope,
+                                                        long obs /* floats between the volumes of two samples */) {
   constexpr int BUF = SRC_FLOATS + X1_FLOATS, RING = NBUF * BUF;
   static_assert(G == 1 || G * RING >= NW * N * 64 * PX, "the accumulator exchange reuses the rings");
   __shared__ __attribute__((aligned(16))) float lds_all[G * RING + TH * SP];  // + pad: prefetch runs a channel ahead
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(NT * G, 3) void fwd_kernel(const float* __restrict_
   }
   const int gy = ty0 + y, gx = tx0 + 4 * xg;
   if (gy >= H || gx >= W) return;
-  float* ob = out + (((long)b * N * N + 3 * wave * N) * H + gy) * W + gx;
+  float* ob = out + (long)b * obs + ((long)(3 * wave * N) * H + gy) * W + gx;
   unsigned sg[PX] = {0u, 0u, 0u, 0u};  // bit k*9+j: this wave's channel (3*wave+k)*9+j is positive
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
                                                     const float* __restrict__ x1,
                                                     const float* __restrict__ x2, float* __restrict__ gx1,
                                                     float* __restrict__ gx2, int B, int C, int H, int W,
-                                                    float inv_c, int mode_base, int nmodes) {
+                                                    float inv_c, int mode_base, int nmodes,
+                                                    long gbs /* batch stride of gout */, long fbs /* of fout */) {
   constexpr int BUF = SRC_FLOATS;
   constexpr int PART = NW * CC * 64 * PX;  // 3072 floats
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + PART];
@@ -286,8 +290,8 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   const long cs = (long)H * W;
   const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * cs;
   float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * cs;
-  const float* gb = gout + (long)b * N * N * cs;
-  const float* fb = ACT == 1 ? fout + (long)b * N * N * cs : nullptr;  // forward output: LeakyReLU derivative
+  const float* gb = gout + (long)b * gbs;
+  const float* fb = ACT == 1 ? fout + (long)b * fbs : nullptr;  // forward output: LeakyReLU derivative
   const int gy = ty0 + y, gx = tx0 + 4 * xg;
   // Every load of the gradient phase is UNCONDITIONAL: a piece outside the image reads the 16 zero bytes
   // of g_zero16 instead of being branched around.  With branches hipcc waits for each load before the
@@ -463,25 +467,28 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
 
 inline int launch_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C, int H, int W,
-                      float slope, hipStream_t st) {
+                      float slope, hipStream_t st, long obs = 0) {
+  if (obs == 0) obs = (long)N * N * H * W;
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B;
   dim3 grid(grid_for_tiles(tiles));
   // many tiles: 4 workgroups per CU hide each other's DMA latency, keep LDS small (2 buffers);
   // few tiles: one workgroup per CU -> deeper ring so its own DMA runs 3 chunks ahead
   const float inv_c = 1.0f / (float)C;
   if (tiles <= 160 && (C / CC) % 4 == 0 && C / CC >= 8)  // few tiles, >= 2 chunks per group: 4 channel groups per workgroup
-    hipLaunchKernelGGL((fwd_kernel<2, 4>), grid, dim3(NT * 4), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
+    hipLaunchKernelGGL((fwd_kernel<2, 4>), grid, dim3(NT * 4), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope, obs);
   // (2 groups at ~1 tile per CU, e.g. 48x80: 23.4 -> 26.1 us -- splitting only pays while CUs are idle)
   else if (tiles >= 768)
-    hipLaunchKernelGGL((fwd_kernel<2, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
+    hipLaunchKernelGGL((fwd_kernel<2, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope, obs);
   else
-    hipLaunchKernelGGL((fwd_kernel<4, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope);
+    hipLaunchKernelGGL((fwd_kernel<4, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope, obs);
   return af_launch_status();
 }
 
 inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign_bits, float slope, const float* x1,
                       const float* x2,
-                      float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st) {
+                      float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st, long gbs = 0, long fbs = 0) {
+  if (gbs == 0) gbs = (long)N * N * H * W;
+  if (fbs == 0) fbs = (long)N * N * H * W;
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B * nmodes;
@@ -493,7 +500,7 @@ inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign
   const int mb = gx1 ? 0 : 1;
 #define CORR_V2_BWD(NB, ACT)                                                                                      \
   hipLaunchKernelGGL((bwd_kernel<NB, ACT>), grid, dim3(NT), 0, st, gout, fout, sign_bits, slope, x1, x2, gx1, gx2, \
-                     B, C, H, W, inv_c, mb, nmodes)
+                     B, C, H, W, inv_c, mb, nmodes, gbs, fbs)
   if (tiles >= 768) {
     if (act == 2) CORR_V2_BWD(2, 2); else if (act == 1) CORR_V2_BWD(2, 1); else CORR_V2_BWD(2, 0);
   } else {

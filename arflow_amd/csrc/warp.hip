@@ -18,6 +18,18 @@ namespace {
 // coalesced rows: dword-granular gathers straight from global spent 2.4x the bytes in L1->L2 traffic
 // and ran at 25 % of the HBM roofline) and the four taps of every pixel are then read from LDS.
 // Falls back to direct (batched) gathers when the window does not fit or rows are not 16-byte aligned.
+// source storage: float, or bf16 bit patterns (opt-in bf16 storage of the warped features, SURVEY section 8(f)-4;
+// sampling arithmetic and outputs stay fp32)
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {  // 4 bf16 = one 8-byte load
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u));
+}
+
 namespace fwd_win {
 constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24;
 // CCH = channels staged per chunk.  These kernels are latency-bound chains (flow -> taps -> box -> window -> taps),
@@ -29,8 +41,8 @@ constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24;
 // thread are issued before the first LDS write and none is branched around (a slot outside the window
 // reads the plane's first 16 bytes instead): with `if (inside) win[..] = load` per slot hipcc waits for
 // every load before issuing the next -- 2 x CCH serialised round trips per chunk.
-template <int WQ, int CCH>
-__device__ __forceinline__ void stage_window(float* __restrict__ win, const float* __restrict__ sp, int c0, int C,
+template <int WQ, int CCH, typename TS>
+__device__ __forceinline__ void stage_window(float* __restrict__ win, const TS* __restrict__ sp, int c0, int C,
                                              int ss, int Ws, int ax0, int by0, int bh) {
   constexpr int WP = 4 * WQ, ITER = (HMAX * WQ + NT - 1) / NT;
   const int per = bh * WQ;
@@ -46,7 +58,7 @@ __device__ __forceinline__ void stage_window(float* __restrict__ win, const floa
     const long off = ok[it] ? (long)(by0 + r) * Ws + ax0 + 4 * xs : 0;
 #pragma unroll
     for (int c = 0; c < CCH; ++c)
-      v[c][it] = *reinterpret_cast<const float4*>(sp + (long)min(c0 + c, C - 1) * ss + off);
+      v[c][it] = load4(sp + (long)min(c0 + c, C - 1) * ss + off);
   }
 #pragma unroll
   for (int it = 0; it < ITER; ++it)
@@ -55,14 +67,14 @@ __device__ __forceinline__ void stage_window(float* __restrict__ win, const floa
       if (ok[it] && c0 + c < C) *reinterpret_cast<float4*>(win + c * HMAX * WP + dst[it]) = v[c][it];
 }
 
-template <int WQ, int CCH>  // window row = WQ float4
-__device__ __forceinline__ void run(float* __restrict__ win, const float* __restrict__ sp, float* __restrict__ op,
+template <int WQ, int CCH, typename TS>  // window row = WQ float4
+__device__ __forceinline__ void run(float* __restrict__ win, const TS* __restrict__ sp, float* __restrict__ op,
                                     const TapPlan& p, bool inside, int C, int ss, int os, int Ws, int ax0, int by0,
                                     int bh, int l0, int l1, int l2, int l3) {
   constexpr int WP = 4 * WQ;
   // channels are independent: at small levels they are spread over gridDim.y workgroups per tile
   for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
-    stage_window<WQ, CCH>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
+    stage_window<WQ, CCH, TS>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
     __syncthreads();
     if (inside) {
 #pragma unroll
@@ -82,8 +94,8 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
 }
 }  // namespace fwd_win
 
-template <int CCH>
-__global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ src,
+template <int CCH, typename TS = float>
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const TS* __restrict__ src,
                                                        const float* __restrict__ flow,
                                                        float* __restrict__ out, float* __restrict__ valid,
                                                        int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
   const int aw = box[2] - ax0 + 1;            // floats needed from ax0
   const bool empty = box[2] < bx0;
   const int ss = Hs * Ws, os = H * W;
-  const float* sp = src + (long)b * C * ss;
+  const TS* sp = src + (long)b * C * ss;
   float* op = out + (long)b * C * os + (long)y * W + x;
 
   if (!empty && (Ws & 3) == 0 && bh <= HMAX && aw <= 72) {
@@ -151,10 +163,10 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
     const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
     if (aw <= 48)
-      run<12, CCH>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 48 + cxa, cya * 48 + cxb, cyb * 48 + cxa,
+      run<12, CCH, TS>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 48 + cxa, cya * 48 + cxb, cyb * 48 + cxa,
               cyb * 48 + cxb);
     else
-      run<18, CCH>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 72 + cxa, cya * 72 + cxb, cyb * 72 + cxa,
+      run<18, CCH, TS>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 72 + cxa, cya * 72 + cxb, cyb * 72 + cxa,
               cyb * 72 + cxb);
     return;
   }
@@ -169,9 +181,9 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
     float a[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float* s = sp + (long)min(c0 + u, C - 1) * ss;  // clamped: the loads stay unconditional
+      const TS* s = sp + (long)min(c0 + u, C - 1) * ss;  // clamped: the loads stay unconditional
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a[u][k] = s[p.o[k]];
+      for (int k = 0; k < 4; ++k) a[u][k] = to_f32(s[p.o[k]]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -223,8 +235,8 @@ __device__ __forceinline__ TileBox tile_bbox(const Taps& t, int (*red)[4], int* 
 // ------------------------------------------------------------------------------------------------
 namespace flow_grad {
 using fwd_win::HMAX;
-template <int WQ, int CCH>
-__device__ __forceinline__ void run(float* __restrict__ win, const float* __restrict__ sp,
+template <int WQ, int CCH, typename TS>
+__device__ __forceinline__ void run(float* __restrict__ win, const TS* __restrict__ sp,
                                     const float* __restrict__ gop, const TapPlan& p, const Taps& t, bool inside, int C,
                                     int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
                                     float& gix, float& giy) {
@@ -233,7 +245,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
     float g[CCH];
 #pragma unroll
     for (int c = 0; c < CCH; ++c) g[c] = (inside && c0 + c < C) ? gop[(long)(c0 + c) * os] : 0.f;
-    fwd_win::stage_window<WQ, CCH>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
+    fwd_win::stage_window<WQ, CCH, TS>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CCH; ++c) {
@@ -248,9 +260,9 @@ __device__ __forceinline__ void run(float* __restrict__ win, const float* __rest
 }
 }  // namespace flow_grad
 
-template <int CCH>
+template <int CCH, typename TS = float>
 __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restrict__ gout,
-                                                            const float* __restrict__ src,
+                                                            const TS* __restrict__ src,
                                                             const float* __restrict__ flow, float* __restrict__ gflow,
                                                             int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
                                                             int pad, int align, int norm) {
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
   const int bh = bb.y1 - bb.y0 + 1, ax0 = bb.x0 & ~3, aw = bb.x1 - ax0 + 1;
   const bool empty = bb.x1 < bb.x0;
   const int ss = Hs * Ws, os = H * W;
-  const float* sp = src + (long)b * C * ss;
+  const TS* sp = src + (long)b * C * ss;
   const float* gop = gout + (long)b * C * os + (long)y * W + x;
   float gix = 0.f, giy = 0.f;
   if (!empty && (Ws & 3) == 0 && bh <= HMAX && aw <= 72) {
@@ -281,16 +293,16 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
     const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
     const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
     if (aw <= 48)
-      flow_grad::run<12, CCH>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa, cya * 48 + cxb,
+      flow_grad::run<12, CCH, TS>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa, cya * 48 + cxb,
                          cyb * 48 + cxa, cyb * 48 + cxb, gix, giy);
     else
-      flow_grad::run<18, CCH>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa, cya * 72 + cxb,
+      flow_grad::run<18, CCH, TS>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa, cya * 72 + cxb,
                          cyb * 72 + cxa, cyb * 72 + cxb, gix, giy);
   } else if (inside && !empty) {
     for (int c = blockIdx.y; c < C; c += gridDim.y) {  // direct gathers (window too large or unaligned rows)
       const float g = gop[(long)c * os];
-      const float* s = sp + (long)c * ss;
-      float a0 = s[p.o[0]], a1 = s[p.o[1]], a2 = s[p.o[2]], a3 = s[p.o[3]];
+      const TS* s = sp + (long)c * ss;
+      float a0 = to_f32(s[p.o[0]]), a1 = to_f32(s[p.o[1]]), a2 = to_f32(s[p.o[2]]), a3 = to_f32(s[p.o[3]]);
       asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
       const float nw = p.ok[0] ? a0 : 0.f, ne = p.ok[1] ? a1 : 0.f, sw = p.ok[2] ? a2 : 0.f, se = p.ok[3] ? a3 : 0.f;
       gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
@@ -774,5 +786,61 @@ extern "C" int arflow_occ_bidir(const float* flow12, const float* flow21, float*
   const int bx = pick_bx(W);
   hipLaunchKernelGGL(occ_bidir_kernel, pixel_grid(B, H, W, bx), dim3(bx), 0, (hipStream_t)stream, flow12,
                      flow21, out, H, W, bstride12, bstride21, scale, bias);
+  return af_launch_status();
+}
+
+// ---- bf16 STORAGE of the warped features (opt-in): src holds bf16 bit patterns; coordinates,
+// bilinear arithmetic, the output and both gradients are fp32.  (d/d src never reads src: arflow_warp_bwd's kernel.)
+extern "C" int arflow_warp_fwd_bf16(const unsigned short* src, const float* flow, float* out, float* valid, int B, int C,
+                                    int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode, int align_corners,
+                                    int norm_mode, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(src);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  hipLaunchKernelGGL((warp_fwd_kernel<2, bf16_t>), dim3(af_grid_for_tiles(tiles), channel_split(tiles, C)), dim3(256), 0,
+                     (hipStream_t)stream, src, flow, out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode,
+                     align_corners, norm_mode);
+  return af_launch_status();
+}
+
+extern "C" int arflow_warp_bwd_bf16(const float* gout, const unsigned short* src, const float* flow, float* gsrc,
+                                    float* gflow, int B, int C, int Hs, int Ws, int H, int W, long flow_bstride,
+                                    int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gout);
+  AF_REQUIRE_PTR(src);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+  if (!gsrc && !gflow) return ARFLOW_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (gsrc) {
+    hipError_t e = hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * C * Hs * Ws, st);
+    if (e != hipSuccess) return af_hip_status(e);
+  }
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  const unsigned nsplit = channel_split(tiles, C);
+  if (gsrc)
+    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
+                       flow, gsrc, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  if (gsrc && gflow) AF_LAUNCH_CHECK();
+  if (gflow) {
+    if (nsplit > 1) {
+      hipError_t e = hipMemsetAsync(gflow, 0, sizeof(float) * (size_t)B * 2 * H * W, st);
+      if (e != hipSuccess) return af_hip_status(e);
+    }
+    hipLaunchKernelGGL((warp_bwd_flow_kernel<2, bf16_t>), dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
+                       src, flow, gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  }
   return af_launch_status();
 }

@@ -157,10 +157,133 @@ class CorrelationFunction(torch.autograd.Function):
         return g1, g2, None, None
 
 
-def correlation(x1, x2, max_displacement=4, negative_slope=1.0):
+def _storage(storage):
+    if storage in (None, 'fp32', torch.float32):
+        return None
+    if storage in ('bf16', torch.bfloat16):
+        return 'bf16'
+    raise ValueError('storage must be None / "fp32" or "bf16" / torch.bfloat16, got %r' % (storage,))
+
+
+class CorrelationBF16Function(torch.autograd.Function):
+    """Cost volume with the features STORED as bf16 (opt-in; the reference's native path
+    dispatches half as well, correlation_cuda_kernel.cu:352,369): the fp32 inputs are rounded to bf16 once, the kernels
+    read (and autograd keeps) 2 bytes per feature, products are accumulated in fp32, volume and gradients are fp32."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, max_displacement, negative_slope):
+        for t in (x1, x2):
+            if not t.is_cuda:
+                raise _lib.ArflowHipError('arflow_amd ops run on the GPU only')
+        if x1.shape != x2.shape or x1.dim() != 4:
+            raise ValueError('correlation expects two [B,C,H,W] tensors of equal shape')
+        B, C, H, W = x1.shape
+        d, slope = int(max_displacement), float(negative_slope)
+        b1, b2 = x1.to(torch.bfloat16).contiguous(), x2.to(torch.bfloat16).contiguous()
+        out = torch.empty(B, (2 * d + 1) ** 2, H, W, device=x1.device, dtype=torch.float32)
+        with torch.cuda.device_of(x1):
+            _call('arflow_corr_fwd_bf16', _p(b1), _p(b2), _p(out), B, C, H, W, d, slope, _stream(), key=(B, C, H, W, d, 0))
+        ctx.save_for_backward(b1, b2, out if slope != 1.0 else None)
+        ctx.d, ctx.slope = d, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        b1, b2, fout = ctx.saved_tensors
+        B, C, H, W = b1.shape
+        gout = gout.contiguous()
+        g1 = torch.empty(B, C, H, W, device=b1.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty(B, C, H, W, device=b1.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device_of(b1):
+            _call('arflow_corr_bwd_bf16', _p(gout), _p(fout), _p(b1), _p(b2), _p(g1), _p(g2), B, C, H, W, ctx.d, ctx.slope,
+                  _stream(), key=(B, C, H, W, ctx.d, 0 if fout is None else (2 * ctx.d + 1) ** 2))
+        return g1, g2, None, None
+
+
+def correlation(x1, x2, max_displacement=4, negative_slope=1.0, storage=None):
     """Cost volume, optionally with the LeakyReLU every caller applies right after it fused into the
-    kernel's store stage (and its derivative into the backward's load stage)."""
+    kernel's store stage (and its derivative into the backward's load stage).  storage='bf16' (opt-in) keeps the
+    features as bf16 in HBM: fp32 accumulation, fp32 volume and gradients."""
+    if _storage(storage) == 'bf16':
+        return CorrelationBF16Function.apply(x1, x2, max_displacement, negative_slope)
     return CorrelationFunction.apply(x1, x2, max_displacement, negative_slope)
+
+
+class CorrConcatFunction(torch.autograd.Function):
+    """cat([*before, leaky_relu(corr(x1, x2)), *after], dim=1) with the cost volume written by the kernel STRAIGHT
+    into its channel slot of the concatenated buffer (arflow_corr_fwd_strided), and its gradient read in place from
+    the gradient of that buffer (arflow_corr_bwd_strided): the decoders of the reference concatenate the volume with
+    features and flow right after computing it (models/pwclite_uflow.py:218-222, models/pwclite.py:187-189,
+    models/uflow_model.py:192-198) -- 81 of the 115-147 channels of that copy, forward, and a contiguous() of the
+    81-channel gradient slice, backward, disappear.  The other members are copied into their slots."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, max_displacement, negative_slope, n_before, *others):
+        _need_gpu(x1, x2, *others)
+        B, C, H, W = x1.shape
+        d, slope = int(max_displacement), float(negative_slope)
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        nvol = (2 * d + 1) ** 2
+        chans = [int(t.shape[1]) for t in others]
+        c0 = sum(chans[:n_before])
+        ctot = nvol + sum(chans)
+        buf = torch.empty(B, ctot, H, W, device=x1.device, dtype=torch.float32)
+        planes = _lib.load().arflow_corr_sign_planes(C, W, d) if slope != 1.0 else 0
+        sign = torch.empty(B, planes, H, W, device=x1.device, dtype=torch.int32) if planes else None
+        vol = buf[:, c0:c0 + nvol]
+        with torch.cuda.device_of(x1):
+            _call('arflow_corr_fwd_strided', _p(x1), _p(x2), vol.data_ptr(), ctot * H * W, _p(sign), B, C, H, W, d, slope,
+                  _stream(), key=(B, C, H, W, d, planes))
+        off = 0
+        for k, t in enumerate(others):
+            if k == n_before:
+                off += nvol
+            buf[:, off:off + chans[k]].copy_(t)
+            off += chans[k]
+        # fast path with sign words keeps 12 B/px for the LeakyReLU derivative; otherwise the buffer itself (its
+        # volume slot) is the saved forward output
+        ctx.save_for_backward(x1, x2, sign if planes else (buf if slope != 1.0 else None))
+        ctx.cfg = (d, slope, planes, n_before, chans, c0, nvol, ctot)
+        return buf
+
+    @staticmethod
+    def backward(ctx, gbuf):
+        x1, x2, act = ctx.saved_tensors
+        d, slope, planes, n_before, chans, c0, nvol, ctot = ctx.cfg
+        B, C, H, W = x1.shape
+        gbuf = gbuf.contiguous()
+        sign, fout = (act, None) if planes else (None, act)
+        g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        gvol = gbuf[:, c0:c0 + nvol]
+        with torch.cuda.device_of(x1):
+            _call('arflow_corr_bwd_strided', gvol.data_ptr(), ctot * H * W,
+                  None if fout is None else fout[:, c0:c0 + nvol].data_ptr(), ctot * H * W, _p(sign), _p(x1), _p(x2),
+                  _p(g1), _p(g2), B, C, H, W, d, slope, _stream(),
+                  key=(B, C, H, W, d, 0 if act is None else (planes or nvol)))
+        gothers, off = [], 0
+        for k, c in enumerate(chans):
+            if k == n_before:
+                off += nvol
+            gothers.append(gbuf[:, off:off + c] if ctx.needs_input_grad[5 + k] else None)
+            off += c
+        return (g1, g2, None, None, None) + tuple(gothers)
+
+
+_CORR_CONCAT = __import__('os').environ.get('ARFLOW_CORR_CONCAT', '1') != '0'  # A/B switch for tools/ and bench.py
+
+
+def corr_concat_supported(C, W, max_displacement=4):
+    return bool(_lib.load().arflow_corr_strided_supported(int(C), int(W), int(max_displacement)))
+
+
+def correlation_concat(x1, x2, before=(), after=(), max_displacement=4, negative_slope=1.0):
+    """torch.cat([*before, leaky_relu(correlation(x1, x2)), *after], 1) without ever copying the cost volume (shapes
+    the strided kernels do not take fall back to the plain op + torch.cat)."""
+    B, C, H, W = x1.shape
+    if x1.is_cuda and _CORR_CONCAT and corr_concat_supported(C, W, max_displacement):
+        return CorrConcatFunction.apply(x1, x2, max_displacement, negative_slope, len(before), *before, *after)
+    return torch.cat(list(before) + [correlation(x1, x2, max_displacement, negative_slope)] + list(after), 1)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -292,7 +415,44 @@ class WarpFunction(torch.autograd.Function):
         return gsrc, gflow, None, None, None, None
 
 
-def warp(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW):
+class WarpBF16Function(torch.autograd.Function):
+    """Bilinear warp with the SOURCE stored as bf16 (opt-in): sampling arithmetic, output and
+    both gradients fp32; the source is rounded to bf16 once and kept as such for the backward."""
+
+    @staticmethod
+    def forward(ctx, src, flow, pad, align_corners, norm):
+        if not (src.is_cuda and flow.is_cuda):
+            raise _lib.ArflowHipError('arflow_amd ops run on the GPU only')
+        sb = src.to(torch.bfloat16).contiguous()
+        flow, fbs = _flow_view(flow.float())
+        B, C, Hs, Ws = sb.shape
+        _, _, H, W = flow.shape
+        out = torch.empty(B, C, H, W, device=src.device, dtype=torch.float32)
+        with torch.cuda.device_of(src):
+            _call('arflow_warp_fwd_bf16', _p(sb), _p(flow), _p(out), None, B, C, Hs, Ws, H, W, fbs, pad,
+                  int(bool(align_corners)), norm, _stream(), key=(B, C, H, W))
+        ctx.save_for_backward(sb, flow)
+        ctx.cfg = (pad, int(bool(align_corners)), norm, fbs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sb, flow = ctx.saved_tensors
+        pad, ac, norm, fbs = ctx.cfg
+        B, C, Hs, Ws = sb.shape
+        _, _, H, W = flow.shape
+        gout = gout.contiguous()
+        gsrc = torch.empty(B, C, Hs, Ws, device=sb.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty(B, 2, H, W, device=sb.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device_of(sb):
+            _call('arflow_warp_bwd_bf16', _p(gout), _p(sb), _p(flow), _p(gsrc), _p(gflow), B, C, Hs, Ws, H, W, fbs, pad, ac,
+                  norm, _stream(), key=(B, C, H, W, gsrc is not None))
+        return gsrc, gflow, None, None, None
+
+
+def warp(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW, storage=None):
+    if _storage(storage) == 'bf16':
+        return WarpBF16Function.apply(src, flow, PAD[pad], align_corners, norm)
     return WarpFunction.apply(src, flow, PAD[pad], align_corners, norm)
 
 

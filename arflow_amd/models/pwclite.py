@@ -49,9 +49,9 @@ class PWCLite(nn.Module):
             else:
                 flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
                 x2_warp = flow_warp(x2, flow)
-            out_corr_relu = self.corr(x1, x2_warp, negative_slope=0.1)  # corr + LeakyReLU(0.1) in one kernel
             x1_1by1 = self.conv_1x1[l](x1)
-            x_intm, flow_res = self.flow_estimators(torch.cat([out_corr_relu, x1_1by1, flow], dim=1))
+            # corr + LeakyReLU(0.1) in one kernel, written straight into the estimator's concatenated input
+            x_intm, flow_res = self.flow_estimators(self.corr.concat(x1, x2_warp, after=(x1_1by1, flow), negative_slope=0.1))
             flow = flow + flow_res
             flow = flow + self.context_networks(torch.cat([x_intm, flow], dim=1))
             flows.append(flow)

@@ -40,8 +40,12 @@ class PWCLiteUflow(nn.Module):
         self.feature_pyramid_extractor = FeatureExtractor(self.num_chs, convs_per_level=3, rescale_input=True)
         self.n_frames = cfg.n_frames
         self.reduce_dense = cfg.reduce_dense
+        # opt-in: cfg.feature_storage = 'bf16' keeps the correlation / warp inputs as bf16 in HBM (fp32 arithmetic);
+        # absent or 'fp32' = the reference's fp32 path
+        fs = cfg.get('feature_storage', 'fp32') if hasattr(cfg, 'get') else 'fp32'
+        self.feature_storage = torch.bfloat16 if fs == 'bf16' else None
         self.corr = Correlation(pad_size=self.search_range, kernel_size=1, max_displacement=self.search_range,
-                                stride1=1, stride2=1, corr_multiply=1)
+                                stride1=1, stride2=1, corr_multiply=1, storage_dtype=self.feature_storage)
         self.dim_corr = (self.search_range * 2 + 1) ** 2
         est = FlowEstimatorReduce if self.reduce_dense else FlowEstimatorDense
         self.flow_estimators = nn.ModuleList()
@@ -82,15 +86,13 @@ class PWCLiteUflow(nn.Module):
                 x2_warp = x2
             else:
                 flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=self.align_corners)
-                x2_warp = flow_warp(x2, flow, align_corners=self.align_corners, pad=self.warp_pad)
+                x2_warp = flow_warp(x2, flow, align_corners=self.align_corners, pad=self.warp_pad,
+                                    **({'storage_dtype': self.feature_storage} if self.feature_storage is not None else {}))
             if self.feature_norm:
                 x1, x2_warp = normalize_features([x1, x2_warp])
-            out_corr_relu = self.corr(x1, x2_warp, negative_slope=0.1)  # corr + LeakyReLU(0.1) in one kernel
-            if l == 0:
-                act, flow_res = self.flow_estimators[l](torch.cat([out_corr_relu, x1, flow], dim=1))
-            else:
-                act_deconv = self.deconv_networks[l - 1](act)
-                act, flow_res = self.flow_estimators[l](torch.cat([out_corr_relu, x1, flow, act_deconv], dim=1))
+            # corr + LeakyReLU(0.1) in one kernel, written straight into the estimator's concatenated input
+            after = (x1, flow) if l == 0 else (x1, flow, self.deconv_networks[l - 1](act))
+            act, flow_res = self.flow_estimators[l](self.corr.concat(x1, x2_warp, after=after, negative_slope=0.1))
             if drops is not None:
                 flow_res = flow_res * drops[l]
                 act = act * drops[l]

@@ -6,7 +6,7 @@ import torch.nn.functional as func
 
 from .. import functional as AF
 from .. import uflow_utils
-from ..correlation import compute_cost_volume
+from ..correlation import cost_volume_concat
 from . import blocks
 from .blocks import ConvAct, init_conv_weights, pair_batches
 
@@ -126,12 +126,10 @@ class PWCFlow(nn.Module):
             f1n, w2n = normalize_features([features1, warped2], normalize=self._normalize_before_cost_volume,
                                           center=self._normalize_before_cost_volume,
                                           moments_across_channels=True, moments_across_images=True)
-            cost_volume = compute_cost_volume(f1n, w2n, max_displacement=4,
-                                              negative_slope=self._leaky_relu_alpha)  # fused LeakyReLU
-            if flow_up is None:
-                x_in = torch.cat([cost_volume, features1], dim=1)
-            else:
-                x_in = torch.cat([context_up, flow_up, cost_volume, features1], dim=1)
+            # cost volume + fused LeakyReLU, written straight into its slot of the decoder's concatenated input
+            before = () if flow_up is None else (context_up, flow_up)
+            x_in = cost_volume_concat(f1n, w2n, before, (features1,), max_displacement=4,
+                                      negative_slope=self._leaky_relu_alpha)
             layers = self._flow_layers[level]
             x_out = None
             for layer in layers[:-1]:

@@ -44,8 +44,12 @@ def synthetic_pairs(batch, height, width, frames=2, device='cuda', seed=0):
 
 
 class TrainStep:
-    def __init__(self, workload, device, lr=1e-4, seed=0, n_buckets=4):
+    def __init__(self, workload, device, lr=1e-4, seed=0, n_buckets=4, feature_storage='fp32'):
         mcfg, lcfg = WORKLOADS[workload]
+        if feature_storage != 'fp32':
+            if mcfg['type'] != 'pwclite_uflow':
+                raise ValueError('feature_storage=%r is wired into the pwclite_uflow model only' % feature_storage)
+            mcfg = dict(mcfg, feature_storage=feature_storage)
         self.model_cfg, self.loss_cfg = AttrDict(mcfg), AttrDict(lcfg)
         torch.manual_seed(seed)
         self.model = get_model(self.model_cfg)

@@ -4,11 +4,12 @@ import torch
 from . import functional as AF
 
 
-def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True):
-    """utils/warp_utils.py:83-90."""
+def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True, storage_dtype=None):
+    """utils/warp_utils.py:83-90.  storage_dtype=torch.bfloat16 (opt-in, not in the reference's signature): keep the
+    warped source as bf16 in HBM, fp32 arithmetic / output / gradients."""
     if mode != 'bilinear':
         raise NotImplementedError("only mode='bilinear' is implemented (the reference never uses another)")
-    return AF.warp(x, flow, pad=pad, align_corners=align_corners, norm=AF.NORM_ARFLOW)
+    return AF.warp(x, flow, pad=pad, align_corners=align_corners, norm=AF.NORM_ARFLOW, storage=storage_dtype)
 
 
 def get_corresponding_map(data):

@@ -67,14 +67,27 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def algorithmic_bytes(name, shape):
     """Compulsory HBM bytes of one launch (each input read once, each output written once, fp32):
     SURVEY section 8(d).  `shape` is the tuple recorded by arflow_amd.functional for the call."""
-    if name == 'arflow_corr_fwd':
+    if name in ('arflow_corr_fwd', 'arflow_corr_fwd_strided'):
         B, C, H, W, d = shape[:5]
         act = shape[5] if len(shape) > 5 else 0  # fused LeakyReLU: sign words written per pixel
         return 4 * B * H * W * (2 * C + (2 * d + 1) ** 2 + act)
-    if name == 'arflow_corr_bwd':
+    if name in ('arflow_corr_bwd', 'arflow_corr_bwd_strided'):
         B, C, H, W, d = shape[:5]
         act = int(shape[5]) if len(shape) > 5 else 0  # fused LeakyReLU: 3 sign words (fast path) or the 81-ch output read per pixel
         return 4 * B * H * W * ((2 * d + 1) ** 2 + act + 4 * C)
+    if name == 'arflow_corr_fwd_bf16':  # features at 2 bytes
+        B, C, H, W, d = shape[:5]
+        return B * H * W * (2 * 2 * C + 4 * (2 * d + 1) ** 2)
+    if name == 'arflow_corr_bwd_bf16':
+        B, C, H, W, d = shape[:5]
+        act = int(shape[5]) if len(shape) > 5 else 0
+        return B * H * W * (4 * ((2 * d + 1) ** 2 + act) + 2 * 2 * C + 4 * 2 * C)
+    if name == 'arflow_warp_fwd_bf16':
+        B, C, H, W = shape
+        return B * H * W * (2 * C + 4 * C + 8)
+    if name == 'arflow_warp_bwd_bf16':
+        B, C, H, W, with_src = shape
+        return B * H * W * (4 * C + 2 * C + 16 + (4 * C if with_src else 0))
     if name == 'arflow_featnorm_fwd':
         B, n = shape
         return 4 * B * n * 4  # two tensors in, two out (the second read of the inputs is not compulsory)
@@ -156,10 +169,10 @@ def valu_slots(name, shape):
     if name == 'arflow_photo_bwd':
         B, C, H, W = shape  # window coefficients (as forward) + 9 windows x 3 fma per pixel
         return B * C * H * W * (5 + 45 + 45 + 2 * T + 27)
-    if name == 'arflow_corr_fwd':
+    if name in ('arflow_corr_fwd', 'arflow_corr_fwd_strided'):
         B, C, H, W, d = shape[:5]
         return B * H * W * (2 * d + 1) ** 2 * C
-    if name == 'arflow_corr_bwd':
+    if name in ('arflow_corr_bwd', 'arflow_corr_bwd_strided'):
         B, C, H, W, d = shape[:5]
         return B * H * W * (2 * d + 1) ** 2 * C * 2
     if name == 'arflow_warp_fwd':
@@ -198,14 +211,14 @@ def kernel_keys(name, shape):
     elif name in ('arflow_photo_fwd', 'arflow_photo_bwd'):
         B, C, H, W = shape
         keys = ['photo4::%s_kernel|%d' % (name[-3:], grid(cdiv(W, 64) * cdiv(H, 16) * B, 256))]
-    elif name == 'arflow_corr_fwd':
+    elif name in ('arflow_corr_fwd', 'arflow_corr_fwd_strided'):
         B, C, H, W = shape[:4]
         tiles = cdiv(W, 32) * cdiv(H, 8) * B
         if tiles <= 160 and (C // 4) % 4 == 0 and C // 4 >= 8:
             keys = ['corr_v2::fwd_kernel<2, 4>|%d' % grid(tiles, 768)]
         else:
             keys = ['corr_v2::fwd_kernel<%d, 1>|%d' % (2 if tiles >= 768 else 4, grid(tiles, 192))]
-    elif name == 'arflow_corr_bwd':
+    elif name in ('arflow_corr_bwd', 'arflow_corr_bwd_strided'):
         B, C, H, W = shape[:4]
         act = {0: 0, 3: 2}.get(int(shape[5]) if len(shape) > 5 else 0, 1)
         tiles = cdiv(W, 32) * cdiv(H, 8) * B * 2
@@ -354,6 +367,8 @@ def main():
     ap.add_argument('--workload', default='pwclite_uflow+uflow_loss')
     ap.add_argument('--size', type=int, nargs=2, default=[384, 640])
     ap.add_argument('--batch', type=int, default=8, help='image pairs per GPU')
+    ap.add_argument('--feature-storage', choices=['fp32', 'bf16'], default='fp32',
+                    help="opt-in: keep the correlation / warp inputs as bf16 in HBM (fp32 arithmetic); default fp32 = the headline")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--miopen-find', '--miopen-benchmark', dest='miopen_benchmark', action='store_true',
@@ -395,7 +410,7 @@ def main():
     H, W = args.size
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
-    step = TrainStep(args.workload, device, seed=1234)
+    step = TrainStep(args.workload, device, seed=1234, feature_storage=args.feature_storage)
     torch.manual_seed(1000 + rank)  # level-dropout draws differ per rank, like independent workers
     img = synthetic_pairs(args.batch, H, W, frames=step.model_cfg.get('n_frames', 2), device=device, seed=100 + rank)
 
@@ -443,7 +458,9 @@ def main():
             'metric': 'image-pairs/sec fwd+bwd, PWCLite 384x640 bs=8',
             'value': pairs / elapsed, 'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.feature_storage == 'fp32' else 'f32 arithmetic, bf16 storage of the correlation/warp inputs',
+            'data': 'synthetic',
             'config': {'workload': '%s, %dx%d pairs, batch %d per GPU, fwd(both directions)+loss+bwd+allreduce+Adam'
                                    % (args.workload, H, W, args.batch),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,

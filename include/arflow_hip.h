@@ -83,11 +83,25 @@ int arflow_corr_fwd(const float* x1, const float* x2, float* out, unsigned* sign
  * max_disp = 4 fast path: asking for it when arflow_corr_sign_planes(C, W, max_disp) == 0 is ARFLOW_EPARAM. */
 int arflow_corr_sign_planes(int C, int W, int max_disp); /* 3, or 0 if this shape has no sign_bits */
 
+/* The same with the cost volume at a BATCH STRIDE: out[b] starts at out + b * out_bstride floats (>= (2d+1)^2*H*W,
+ * a multiple of 4), channels and rows contiguous inside a sample -- the volume is written straight into channels
+ * [k, k+81) of the [B, Ctot, H, W] buffer the caller's decoder reads as its concatenated input
+ * (torch.cat([out_corr_relu, x1, flow, ...], 1) at models/pwclite_uflow.py:218-222, models/pwclite.py:187-189,
+ * models/uflow_model.py:192-198), so the 81-channel volume is never copied.  Fast path only
+ * (arflow_corr_strided_supported() == 1: max_disp 4, W % 4 == 0, C % 4 == 0), else ARFLOW_EPARAM. */
+int arflow_corr_strided_supported(int C, int W, int max_disp);
+int arflow_corr_fwd_strided(const float* x1, const float* x2, float* out, long out_bstride, unsigned* sign_bits,
+                            int B, int C, int H, int W, int max_disp, float negative_slope, arflow_stream_t stream);
+
 /* Gradients of the above (correlation_cuda.backward, correlation_cuda.cc:89-167; kernels
  * correlation_cuda_kernel.cu:116-300).  gx1 / gx2 may be NULL to skip that gradient. */
 int arflow_corr_bwd(const float* gout, const float* out, const unsigned* sign_bits, const float* x1,
                     const float* x2, float* gx1, float* gx2, int B, int C, int H, int W, int max_disp,
                     float negative_slope, arflow_stream_t stream);
+/* gout (and out, if given) at batch strides: the gradient of the concatenated decoder input is consumed in place. */
+int arflow_corr_bwd_strided(const float* gout, long gout_bstride, const float* out, long out_bstride,
+                            const unsigned* sign_bits, const float* x1, const float* x2, float* gx1, float* gx2, int B,
+                            int C, int H, int W, int max_disp, float negative_slope, arflow_stream_t stream);
 /* With negative_slope != 1 the LeakyReLU derivative is selected per element by the forward's sign_bits
  * (12 bytes per pixel instead of re-reading the 324-byte volume) or, when sign_bits is NULL, by the sign
  * of the forward OUTPUT passed as `out` (as torch's in-place leaky_relu backward does; needs
@@ -250,6 +264,24 @@ int arflow_down4(const float* in, float* out, int planes, int H, int W, arflow_s
  * in [B,1,h,w]; valid/out [B,1,4h,4w]. */
 int arflow_up4_clamp_mul(const float* in, const float* valid, float* out, int B, int h, int w,
                          arflow_stream_t stream);
+
+/* ---- opt-in bf16 STORAGE of the features ----------------------------------------
+ * The reference's native correlation dispatches half-precision tensors as well (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * correlation_cuda_kernel.cu:352,369).  Here: x1 / x2 / src hold bf16 bit patterns (uint16), every product is
+ * accumulated in fp32 and every output and gradient is fp32 -- only the bytes read from HBM (and kept for the
+ * backward) are halved.  max_disp must be 4.  With negative_slope != 1 the backward takes the LeakyReLU derivative
+ * from the sign of the forward output `out`.  Not the default anywhere: callers ask for it explicitly. */
+int arflow_corr_fwd_bf16(const unsigned short* x1, const unsigned short* x2, float* out, int B, int C, int H, int W,
+                         int max_disp, float negative_slope, arflow_stream_t stream);
+int arflow_corr_bwd_bf16(const float* gout, const float* out, const unsigned short* x1, const unsigned short* x2,
+                         float* gx1, float* gx2, int B, int C, int H, int W, int max_disp, float negative_slope,
+                         arflow_stream_t stream);
+int arflow_warp_fwd_bf16(const unsigned short* src, const float* flow, float* out, float* valid, int B, int C, int Hs,
+                         int Ws, int H, int W, long flow_bstride, int pad_mode, int align_corners, int norm_mode,
+                         arflow_stream_t stream);
+int arflow_warp_bwd_bf16(const float* gout, const unsigned short* src, const float* flow, float* gsrc, float* gflow,
+                         int B, int C, int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode, int align_corners,
+                         int norm_mode, arflow_stream_t stream);
 
 #ifdef __cplusplus
 }

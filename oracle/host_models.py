@@ -19,6 +19,9 @@ class OracleCorrelation(nn.Module):
         out = O.correlation(x1, x2, self.d)
         return out if negative_slope == 1.0 else torch.nn.functional.leaky_relu(out, negative_slope)
 
+    def concat(self, x1, x2, before=(), after=(), negative_slope=1.0):
+        return torch.cat(list(before) + [self.forward(x1, x2, negative_slope)] + list(after), 1)
+
 
 @contextlib.contextmanager
 def oracle_ops(model):
@@ -27,7 +30,7 @@ def oracle_ops(model):
     import arflow_amd.models.uflow_model as mum
     import arflow_amd.models.blocks as mb
     saved = [(mp, 'flow_warp', mp.flow_warp), (mpu, 'flow_warp', mpu.flow_warp),
-             (mum, 'compute_cost_volume', mum.compute_cost_volume),
+             (mum, 'cost_volume_concat', mum.cost_volume_concat),
              (mum.uflow_utils, 'resample_flow', mum.uflow_utils.resample_flow),
              (mpu, 'normalize_features', mpu.normalize_features), (mum, 'normalize_features', mum.normalize_features),
              (mb, 'bias_act', mb.bias_act)]
@@ -35,8 +38,8 @@ def oracle_ops(model):
     try:
         mp.flow_warp = O.flow_warp
         mpu.flow_warp = O.flow_warp
-        mum.compute_cost_volume = lambda a, b, max_displacement, negative_slope=1.0: OracleCorrelation(
-            max_displacement)(a, b, negative_slope)
+        mum.cost_volume_concat = lambda a, b, before, after, max_displacement, negative_slope=1.0: OracleCorrelation(
+            max_displacement).concat(a, b, before, after, negative_slope)
         mum.uflow_utils.resample_flow = lambda src, flow: O.resample(src, O.flow_to_warp(flow))
         mpu.normalize_features = O.normalize_features_joint
         mb.bias_act = lambda y, b, s: torch.nn.functional.leaky_relu(y + b.view(1, -1, 1, 1), s)

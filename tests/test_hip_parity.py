@@ -636,3 +636,92 @@ def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, sym, mon
     # without the occlusion term (occ_small = NULL): mask = validity only
     l3, mask3 = AF.census_warp_loss(gray1, gray2, cu(flow), None, 7)
     assert torch.equal(mask3, valid)
+
+
+@pytest.mark.parametrize('shape,slope', [((2, 32, 24, 40), 0.1), ((2, 8, 20, 36), 1.0), ((3, 32, 12, 20), 0.1), ((1, 5, 9, 11), 0.1)],
+                         ids=lambda v: str(v))
+def test_correlation_concat_equals_cat_of_plain_op(AF, oracle, shape, slope):
+    """correlation_concat (arflow_corr_fwd/bwd_strided: the volume written straight into / its gradient read straight
+    from the decoder's concatenated tensor, models/pwclite_uflow.py:218-222) == torch.cat([before, corr, after]) of
+    the plain op, bit for bit, values and every gradient; the last shape has no strided path (falls back to cat)."""
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x1, x2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+    bf = torch.randn(B, 3, H, W, generator=gen)
+    a1, a2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, 2, H, W, generator=gen)
+    go = torch.randn(B, 3 + 81 + C + 2, H, W, generator=gen)
+
+    def run(fused):
+        t = [cu(v).requires_grad_(True) for v in (x1, x2, bf, a1, a2)]
+        if fused:
+            y = AF.correlation_concat(t[0], t[1], (t[2],), (t[3], t[4]), 4, slope)
+        else:
+            y = torch.cat([t[2], AF.correlation(t[0], t[1], 4, slope), t[3], t[4]], 1)
+        return (y,) + torch.autograd.grad(y, t, cu(go))
+    got, ref = run(True), run(False)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert torch.equal(a, b), 'tensor %d differs from cat(plain op): max %g' % (k, float((a - b).abs().max()))
+    # x1 is usually BOTH a correlation input and a member of the concatenation (models/pwclite_uflow.py:220)
+    t1, t2 = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
+    y = AF.correlation_concat(t1, t2, (), (t1,), 4, slope)
+    g1, g2 = torch.autograd.grad(y, [t1, t2], cu(go[:, :81 + C]))
+    r1, r2 = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
+    yr = torch.cat([torch.nn.functional.leaky_relu(oracle.correlation(r1.cpu(), r2.cpu(), 4), slope).cuda(), r1], 1)
+    assert_close(y, yr, 1e-6, 1e-5, 'concat with shared x1')
+    q1, q2 = torch.autograd.grad(yr, [r1, r2], cu(go[:, :81 + C]))
+    assert_close(g1, q1, 1e-5, 1e-4, 'gx1 (corr + identity paths)')
+    assert_close(g2, q2, 1e-5, 1e-4, 'gx2')
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 24, 40), (1, 7, 17, 33), (16, 32, 96, 160)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('slope', [1.0, 0.1])
+def test_bf16_storage_correlation(AF, oracle, shape, slope):
+    """Opt-in bf16 STORAGE of the correlation inputs (the reference's native path dispatches
+    half too, correlation_cuda_kernel.cu:352,369): fp32 accumulation and outputs, so against the oracle run on the
+    bf16-ROUNDED inputs the fp32 tolerances of the fp32 path apply -- the only difference is what is stored."""
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x1, x2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+    go = torch.randn(B, 81, H, W, generator=gen)
+    r1, r2 = x1.bfloat16().float(), x2.bfloat16().float()  # what the kernels see
+    pre = oracle.correlation(r1, r2, 4)
+    if slope != 1.0:
+        go = go * (pre.abs() > 1e-6).float()  # LeakyReLU branch undecided within rounding of 0
+        ref = torch.nn.functional.leaky_relu(pre, slope)
+        gpre = go * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, slope))
+    else:
+        ref, gpre = pre, go
+    q1, q2 = oracle.correlation_backward(gpre, r1, r2, 4)
+    a, b = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
+    y = AF.correlation(a, b, 4, negative_slope=slope, storage='bf16')
+    assert y.dtype == torch.float32
+    assert_close(y, ref, 1e-6, 1e-5, 'bf16-storage corr fwd')
+    g1, g2 = torch.autograd.grad(y, [a, b], cu(go))
+    assert g1.dtype == torch.float32
+    assert_close(g1, q1, 5e-6, 1e-5, 'bf16-storage corr gx1')
+    assert_close(g2, q2, 5e-6, 1e-5, 'bf16-storage corr gx2')
+    # and it is NOT the default: the plain call is the fp32 path
+    assert not torch.equal(AF.correlation(cu(x1), cu(x2), 4, slope), y)
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 24, 40, 'zeros', True), (1, 5, 17, 33, 'border', False), (16, 32, 96, 160, 'zeros', True)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_bf16_storage_warp(AF, oracle, cfg):
+    """Opt-in bf16 storage of the warped source: fp32 sampling, output and gradients; oracle on the rounded source."""
+    from arflow_amd.warp_utils import flow_warp
+    B, C, H, W, pad, ac = cfg
+    gen = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, C, H, W, generator=gen)
+    fl = 2.5 * torch.randn(B, 2, H, W, generator=gen)
+    go = torch.randn(B, C, H, W, generator=gen)
+    xr, fr = x.bfloat16().float().requires_grad_(True), fl.clone().requires_grad_(True)
+    ref = oracle.flow_warp(xr, fr, pad=pad, align_corners=ac)
+    rgx, rgf = torch.autograd.grad(ref, [xr, fr], go)
+    a, f = cu(x).requires_grad_(True), cu(fl).requires_grad_(True)
+    y = flow_warp(a, f, pad=pad, align_corners=ac, storage_dtype=torch.bfloat16)
+    ulp = 2.0 ** -23 * max(H, W)
+    assert_close(y, ref, (2e-6 + 4 * ulp) * float(x.abs().max()), 1e-5, 'bf16-storage warp fwd')
+    gx, gf = torch.autograd.grad(y, [a, f], cu(go))
+    assert gx.dtype == torch.float32
+    assert_close(gx, rgx, 1e-5 * max(1.0, float(rgx.abs().max())), 1e-4, 'bf16-storage warp gsrc')
+    assert_close(gf, rgf, 1e-5 * (C ** 0.5) * float(x.abs().max()) * 4, 2e-4, 'bf16-storage warp gflow')
