@@ -265,8 +265,13 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
                                                     float inv_c, int mode_base, int nmodes,
                                                     long gbs /* batch stride of gout */, long fbs /* of fout */) {
   constexpr int BUF = SRC_FLOATS;
-  constexpr int PART = NW * CC * 64 * PX;  // 3072 floats
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + PART];
+  // Cross-wave sum of the per-wave partials.  Channel c of a chunk is OWNED by wave c % 3: the other two waves
+  // publish their 4-pixel partials for it in LDS, the owner keeps its own in registers and, one iteration later
+  // (after the barrier that also waits for the next chunk's DMA), adds the three and stores.  `part` is double-
+  // buffered so that this ONE barrier per chunk is enough -- the previous form (all three waves publish, barrier,
+  // all threads reduce, and the next chunk's barrier protecting the reuse) had two.
+  constexpr int PART1 = 2 * CC * 64 * PX;  // 2048 floats: two foreign partials per channel
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF + 2 * PART1];
   float* part = lds + NBUF * BUF;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave id in an SGPR
   int xg, y;
@@ -414,21 +419,48 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   // the g loads above are younger than the prologue DMA: drain everything once, then count exactly
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  float own[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // this wave's partials of the channels it owns
+  const bool lane_in = gy < H && gx < W;
+  // add the three waves' partials of chunk `chunk` (in wave order, as before: bit-identical results) and store
+  auto reduce_store = [&](int chunk, int par) {
+    const float* pp = part + par * PART1;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      if (c % NW != wave) continue;  // wave-uniform (wave id lives in an SGPR)
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(pp + ((c * 2 + 0) * 64 + lane) * PX);  // wave (owner+1) % 3
+      const f32x4 s1 = *reinterpret_cast<const f32x4*>(pp + ((c * 2 + 1) * 64 + lane) * PX);  // wave (owner+2) % 3
+      const float* o = own[c / NW];
+      float r[PX];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        const float w0 = wave == 0 ? o[p] : (wave == 1 ? s1[p] : s0[p]);
+        const float w1 = wave == 1 ? o[p] : (wave == 2 ? s1[p] : s0[p]);
+        const float w2 = wave == 2 ? o[p] : (wave == 0 ? s1[p] : s0[p]);
+        r[p] = ((w0 + w1) + w2) * inv_c;
+      }
+      if (lane_in)
+        *reinterpret_cast<float4*>(dstb + (long)((split + chunk * nsplit) * CC + c) * cs + (long)gy * W + gx) =
+            make_float4(r[0], r[1], r[2], r[3]);
+    }
+  };
+  int par = 0;
   for (int ch = 0; ch < nchunk; ++ch) {
-    // chunk ch landed (stores of the previous reduce may still drain: they are older than the DMA of
-    // chunk ch+NBUF-2 only when NBUF == 2, so count conservatively: wait for everything but the
-    // youngest (NBUF-2)*NK DMA instructions)
+    // chunk ch landed and the partials of chunk ch-1 are visible (the waits cover this wave's LDS writes too).
+    // The stores of the previous reduce may still drain: they are older than the DMA of chunk ch+NBUF-2 only
+    // when NBUF == 2, so count conservatively: wait for everything but the youngest (NBUF-2)*NK DMA instructions
     if (ch + NBUF - 2 < nchunk && ch > 0)
       wait_dma_and_barrier<(NBUF - 2) * NK>();
     else
       wait_dma_and_barrier<0>();
     if (ch + NBUF - 1 < nchunk) issue(ch + NBUF - 1);
+    if (ch > 0) reduce_store(ch - 1, par ^ 1);
     const float* cur = lds + (ch % NBUF) * BUF;
     const float* s2 = cur + (y + 3 * wave) * SP + 4 * xg;
+    float* pw = part + par * PART1;
     f32x4 wc[3], wn[3];
     issue_window(s2, wc);
     land_window(wc);
-#pragma unroll 1
+#pragma unroll
     for (int c = 0; c < CC; ++c) {
       const float* sc = s2 + c * SR * SP;
       float pa[PX] = {0.f, 0.f, 0.f, 0.f};
@@ -442,26 +474,20 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
         land_window(wn);
         wc[0] = wn[0], wc[1] = wn[1], wc[2] = wn[2];
       }
-      *reinterpret_cast<float4*>(part + ((wave * CC + c) * 64 + lane) * PX) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+      if (c % NW == wave) {  // wave-uniform: the owner keeps its partial
+#pragma unroll
+        for (int p = 0; p < PX; ++p) own[c / NW][p] = pa[p];
+      } else {
+        const int slot = (wave - c % NW - 1 + NW) % NW;  // 0: wave (owner+1) % 3, 1: wave (owner+2) % 3
+        *reinterpret_cast<float4*>(pw + ((c * 2 + slot) * 64 + lane) * PX) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // sum the three waves' partials: CC*64 float4 results over 192 threads
-    for (int o = threadIdx.x; o < CC * 64; o += NT) {
-      const int c = o >> 6, l = o & 63;
-      int oxg, oy;
-      lane_xy(l, oxg, oy);
-      const float4 p0 = *reinterpret_cast<const float4*>(part + ((0 * CC + c) * 64 + l) * PX);
-      const float4 p1 = *reinterpret_cast<const float4*>(part + ((1 * CC + c) * 64 + l) * PX);
-      const float4 p2 = *reinterpret_cast<const float4*>(part + ((2 * CC + c) * 64 + l) * PX);
-      const int oyy = ty0 + oy, oxx = tx0 + 4 * oxg;
-      if (oyy < H && oxx < W)
-        *reinterpret_cast<float4*>(dstb + (long)((split + ch * nsplit) * CC + c) * cs + (long)oyy * W + oxx) =
-            make_float4((p0.x + p1.x + p2.x) * inv_c, (p0.y + p1.y + p2.y) * inv_c, (p0.z + p1.z + p2.z) * inv_c,
-                        (p0.w + p1.w + p2.w) * inv_c);
-    }
+    par ^= 1;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (nchunk > 0) reduce_store(nchunk - 1, par ^ 1);
 }
 
 inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
@@ -504,7 +530,7 @@ inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign
   if (tiles >= 768) {
     if (act == 2) CORR_V2_BWD(2, 2); else if (act == 1) CORR_V2_BWD(2, 1); else CORR_V2_BWD(2, 0);
   } else {
-    if (act == 2) CORR_V2_BWD(4, 2); else if (act == 1) CORR_V2_BWD(4, 1); else CORR_V2_BWD(4, 0);
+    if (act == 2) CORR_V2_BWD(3, 2); else if (act == 1) CORR_V2_BWD(3, 1); else CORR_V2_BWD(3, 0);  // ring of 3: 46 KB of LDS, 3 workgroups per CU (4: 56 KB, 2)
   }
 #undef CORR_V2_BWD
   return af_launch_status();

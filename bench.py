@@ -222,7 +222,7 @@ def kernel_keys(name, shape):
         B, C, H, W = shape[:4]
         act = {0: 0, 3: 2}.get(int(shape[5]) if len(shape) > 5 else 0, 1)
         tiles = cdiv(W, 32) * cdiv(H, 8) * B * 2
-        keys = ['corr_v2::bwd_kernel<%d, %d>|%d' % (2 if tiles >= 768 else 4, act,
+        keys = ['corr_v2::bwd_kernel<%d, %d>|%d' % (2 if tiles >= 768 else 3, act,
                                                    grid(tiles, 192) * split(tiles, C // 4, 1024))]
     elif name == 'arflow_warp_fwd':
         B, C, H, W = shape
