@@ -29,6 +29,13 @@ PROTOTYPES = {
     'arflow_corr_bwd_bf16': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_warp_fwd_bf16': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_warp_bwd_bf16': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_warp_nearest_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_warp_nearest_bwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_ssim_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_ssim_bwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_corr_general_out_size': [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp],
+    'arflow_corr_general_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_corr_general_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     'arflow_featnorm_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
     'arflow_featnorm_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
     'arflow_bias_act_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_l, c_f, c_fp],

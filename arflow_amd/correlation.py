@@ -18,11 +18,14 @@ class Correlation(nn.Module):
         self.storage = storage_dtype
         if pad_size is None:
             pad_size = max_displacement
-        # models/correlation_native.py:7 swallows these arguments and always computes the
-        # (pad=d, kernel=1, stride=1) volume; the CUDA extension generalises them but no model uses
-        # anything else.  Refuse rather than silently compute something different.
+        # models/correlation_native.py:7 swallows these arguments and always computes the (pad=d, kernel=1, stride=1)
+        # volume; the CUDA extension (correlation_cuda.cc:10-16) honours them.  Every model uses the default, which runs
+        # the tuned kernels; anything else runs the general kernels with the extension's semantics.
+        self.general = None
         if (kernel_size, stride1, stride2) != (1, 1, 1) or pad_size != max_displacement:
-            raise NotImplementedError('only kernel_size=1, stride1=stride2=1, pad_size=max_displacement is supported')
+            if kernel_size % 2 != 1:
+                raise ValueError('kernel_size must be odd')
+            self.general = (int(pad_size), int(kernel_size), int(max_displacement), int(stride1), int(stride2))
         self.max_displacement = int(max_displacement)
         self.output_dim = 2 * self.max_displacement + 1
         self.pad_size = self.max_displacement
@@ -30,13 +33,16 @@ class Correlation(nn.Module):
     def forward(self, x1, x2, negative_slope=1.0):
         """``negative_slope`` != 1 fuses the LeakyReLU the callers apply to the volume
         (models/pwclite.py:183-184) into the kernel; the default is the reference's plain volume."""
+        if self.general is not None:
+            out = AF.correlation_general(x1, x2, *self.general)
+            return out if negative_slope == 1.0 else nn.functional.leaky_relu(out, negative_slope)
         return AF.correlation(x1, x2, self.max_displacement, negative_slope, storage=self.storage)
 
     def concat(self, x1, x2, before=(), after=(), negative_slope=1.0):
         """torch.cat([*before, forward(x1, x2, negative_slope), *after], 1) -- what every decoder does with the volume
         next (models/pwclite.py:187-189, models/pwclite_uflow.py:218-222) -- with the volume written by the kernel
         straight into its channel slot of the concatenated tensor instead of being copied there."""
-        if self.storage is not None:
+        if self.storage is not None or self.general is not None:
             import torch
             return torch.cat(list(before) + [self.forward(x1, x2, negative_slope)] + list(after), 1)
         return AF.correlation_concat(x1, x2, before, after, self.max_displacement, negative_slope)

@@ -308,6 +308,12 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ im_a,
 
 }  // namespace
 
+// radius > 3: the one-thread-per-pixel kernels of generic.hip (TernaryLoss(max_distance > 3), no shipped config)
+int census_any_fwd(const float* im_a, const float* im_b, const float* mask, float* ham, float* dham, float* sums, int B,
+                   int H, int W, int R, hipStream_t st);
+int census_any_bwd(const float* im_a, const float* im_b, const float* gham, const float* scale, float* g_im_b, int B, int H,
+                   int W, int R, hipStream_t st);
+
 extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const float* mask, float* ham,
                                  float* dham, float* sums, int B, int H, int W, int radius,
                                  arflow_stream_t stream) {
@@ -315,12 +321,16 @@ extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const flo
   AF_REQUIRE_PTR(im_a);
   AF_REQUIRE_PTR(im_b);
   AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 8 * 65535, ARFLOW_ESHAPE);
-  AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
+  AF_REQUIRE(radius >= 1 && radius <= 16, ARFLOW_EPARAM);
   if (mask) AF_REQUIRE_PTR(sums);
   hipStream_t st = (hipStream_t)stream;
   if (mask) {
     hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
     if (e != hipSuccess) return af_hip_status(e);
+  }
+  if (radius > 3) {
+    AF_REQUIRE(H <= 65535, ARFLOW_ESHAPE);
+    return census_any_fwd(im_a, im_b, mask, ham, dham, sums, B, H, W, radius, st);
   }
   if ((W & 3) == 0) {
     namespace c4 = census4;
@@ -349,8 +359,12 @@ extern "C" int arflow_census_bwd(const float* im_a, const float* im_b, const flo
   AF_REQUIRE_PTR(gham);
   AF_REQUIRE_PTR(g_im_b);
   AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 8 * 65535, ARFLOW_ESHAPE);
-  AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
+  AF_REQUIRE(radius >= 1 && radius <= 16, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
+  if (radius > 3) {
+    AF_REQUIRE(H <= 65535, ARFLOW_ESHAPE);
+    return census_any_bwd(im_a, im_b, gham, scale, g_im_b, B, H, W, radius, st);
+  }
   if ((W & 3) == 0) {
     namespace c4 = census4;
     dim3 g4(af_grid_for_tiles((long)af_cdiv(W, c4::TXW) * af_cdiv(H, c4::TYH) * B));

@@ -200,6 +200,45 @@ class CorrelationBF16Function(torch.autograd.Function):
         return g1, g2, None, None
 
 
+class CorrelationGeneralFunction(torch.autograd.Function):
+    """Correlation with the CUDA extension's full parameter set (correlation_cuda.cc:10-16: pad_size, kernel_size,
+    max_displacement, stride1, stride2); the configuration every model uses goes through CorrelationFunction."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2):
+        _need_gpu(x1, x2)
+        if x1.shape != x2.shape or x1.dim() != 4:
+            raise ValueError('correlation expects two [B,C,H,W] tensors of equal shape')
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, C, H, W = x1.shape
+        cfg = (int(pad_size), int(kernel_size), int(max_displacement), int(stride1), int(stride2))
+        import ctypes
+        oc, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().arflow_corr_general_out_size(H, W, *cfg, ctypes.addressof(oc), ctypes.addressof(oh),
+                                                            ctypes.addressof(ow)), 'arflow_corr_general_out_size')
+        out = torch.empty(B, oc.value, oh.value, ow.value, device=x1.device, dtype=torch.float32)
+        with torch.cuda.device_of(x1):
+            _call('arflow_corr_general_fwd', _p(x1), _p(x2), _p(out), B, C, H, W, *cfg, _stream())
+        ctx.save_for_backward(x1, x2)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x1, x2 = ctx.saved_tensors
+        B, C, H, W = x1.shape
+        gout = gout.contiguous()
+        g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device_of(x1):
+            _call('arflow_corr_general_bwd', _p(gout), _p(x1), _p(x2), _p(g1), _p(g2), B, C, H, W, *ctx.cfg, _stream())
+        return g1, g2, None, None, None, None, None
+
+
+def correlation_general(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    return CorrelationGeneralFunction.apply(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2)
+
+
 def correlation(x1, x2, max_displacement=4, negative_slope=1.0, storage=None):
     """Cost volume, optionally with the LeakyReLU every caller applies right after it fused into the
     kernel's store stage (and its derivative into the backward's load stage).  storage='bf16' (opt-in) keeps the
@@ -450,6 +489,45 @@ class WarpBF16Function(torch.autograd.Function):
         return gsrc, gflow, None, None, None
 
 
+class WarpNearestFunction(torch.autograd.Function):
+    """flow_warp(mode='nearest') (utils/warp_utils.py:83-90): gradient w.r.t. the source only, like grid_sample."""
+
+    @staticmethod
+    def forward(ctx, src, flow, pad, align_corners, norm):
+        _need_gpu(src, flow)
+        src = src.contiguous()
+        flow, fbs = _flow_view(flow.detach())
+        B, C, Hs, Ws = src.shape
+        _, _, H, W = flow.shape
+        out = torch.empty(B, C, H, W, device=src.device, dtype=torch.float32)
+        with torch.cuda.device_of(src):
+            _call('arflow_warp_nearest_fwd', _p(src), _p(flow), _p(out), B, C, Hs, Ws, H, W, fbs, pad,
+                  int(bool(align_corners)), norm, _stream())
+        ctx.save_for_backward(flow)
+        ctx.cfg = (pad, int(bool(align_corners)), norm, fbs, (B, C, Hs, Ws))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        flow, = ctx.saved_tensors
+        pad, ac, norm, fbs, (B, C, Hs, Ws) = ctx.cfg
+        _, _, H, W = flow.shape
+        gsrc = None
+        if ctx.needs_input_grad[0]:
+            gout = gout.contiguous()
+            gsrc = torch.empty(B, C, Hs, Ws, device=gout.device, dtype=torch.float32)
+            with torch.cuda.device_of(gout):
+                _call('arflow_warp_nearest_bwd', _p(gout), _p(flow), _p(gsrc), B, C, Hs, Ws, H, W, fbs, pad, ac, norm,
+                      _stream())
+        # grid_sample's nearest mode returns a ZERO gradient for the grid (not None)
+        gflow = torch.zeros(B, 2, H, W, device=gout.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        return gsrc, gflow, None, None, None
+
+
+def warp_nearest(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW):
+    return WarpNearestFunction.apply(src, flow, PAD[pad], align_corners, norm)
+
+
 def warp(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW, storage=None):
     if _storage(storage) == 'bf16':
         return WarpBF16Function.apply(src, flow, PAD[pad], align_corners, norm)
@@ -670,6 +748,38 @@ class PhotoSumsFunction(torch.autograd.Function):
             _call('arflow_photo_bwd', _p(im), _p(recons), _p(mask), None, _p(coef), _p(g), B, C, H, W, _stream(),
                   key=(B, C, H, W))
         return None, g, None
+
+
+class SSIMAnyFunction(torch.autograd.Function):
+    """SSIM(x, y, md) distance map of losses/loss_blocks.py:65-84 for any md (md = 1: SSIMFunction, the tiled kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, y, md):
+        _need_gpu(x, y)
+        x, y = x.contiguous(), y.contiguous()
+        B, C, H, W = x.shape
+        md = int(md)
+        out = torch.empty(B, C, H - 2 * md, W - 2 * md, device=x.device, dtype=torch.float32)
+        with torch.cuda.device_of(x):
+            _call('arflow_ssim_fwd', _p(x), _p(y), _p(out), B, C, H, W, md, _stream())
+        ctx.save_for_backward(x, y)
+        ctx.md = md
+        return out
+
+    @staticmethod
+    def backward(ctx, gmap):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gmap = gmap.contiguous()
+        gx = gy = None
+        with torch.cuda.device_of(x):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                _call('arflow_ssim_bwd', _p(x), _p(y), _p(gmap), _p(gx), B, C, H, W, ctx.md, _stream())
+            if ctx.needs_input_grad[1]:
+                gy = torch.empty_like(y)  # SSIM is symmetric in its arguments
+                _call('arflow_ssim_bwd', _p(y), _p(x), _p(gmap), _p(gy), B, C, H, W, ctx.md, _stream())
+        return gx, gy, None
 
 
 class SSIMFunction(torch.autograd.Function):

@@ -17,8 +17,8 @@ def penalty_uflow(x):
 
 def TernaryLoss(im, im_warp, max_distance=1, sum_dist=False):
     """losses/loss_blocks.py:12-62 -> (dist, mask)."""
-    if not 1 <= max_distance <= 3:
-        raise NotImplementedError('max_distance must be 1..3')
+    if not 1 <= max_distance <= 16:
+        raise ValueError('max_distance must be in 1..16')  # 1..3: the tiled kernels; beyond: the plain ones
     dist = AF.TernaryDistFunction.apply(im, im_warp, max_distance)
     if not sum_dist:
         dist = dist / float((2 * max_distance + 1) ** 2)
@@ -31,7 +31,7 @@ def TernaryLoss(im, im_warp, max_distance=1, sum_dist=False):
 def SSIM(x, y, md=1):
     """losses/loss_blocks.py:65-84."""
     if md != 1:
-        raise NotImplementedError('only md=1 (3x3) is implemented; the reference never uses another')
+        return AF.SSIMAnyFunction.apply(x, y, md)  # any window; md = 1 (every shipped config) runs the tiled kernel
     return AF.SSIMFunction.apply(x, y)
 
 

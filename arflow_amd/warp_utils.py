@@ -7,8 +7,10 @@ from . import functional as AF
 def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True, storage_dtype=None):
     """utils/warp_utils.py:83-90.  storage_dtype=torch.bfloat16 (opt-in, not in the reference's signature): keep the
     warped source as bf16 in HBM, fp32 arithmetic / output / gradients."""
+    if mode == 'nearest':
+        return AF.warp_nearest(x, flow, pad=pad, align_corners=align_corners, norm=AF.NORM_ARFLOW)
     if mode != 'bilinear':
-        raise NotImplementedError("only mode='bilinear' is implemented (the reference never uses another)")
+        raise NotImplementedError("mode must be 'bilinear' or 'nearest' ('bicubic' is not implemented; no caller uses it)")
     return AF.warp(x, flow, pad=pad, align_corners=align_corners, norm=AF.NORM_ARFLOW, storage=storage_dtype)
 
 

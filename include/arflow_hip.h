@@ -265,6 +265,36 @@ int arflow_down4(const float* in, float* out, int planes, int H, int W, arflow_s
 int arflow_up4_clamp_mul(const float* in, const float* valid, float* out, int B, int h, int w,
                          arflow_stream_t stream);
 
+/* ---- the rest of the reference's parameter space (no shipped config uses these values; plain kernels) ----------
+ * flow_warp(mode='nearest') (utils/warp_utils.py:83-90 -> grid_sample nearest: border clips the coordinate, index =
+ * nearbyint, out of range reads 0).  No gradient w.r.t. the flow (grid_sample's nearest mode has none). */
+int arflow_warp_nearest_fwd(const float* src, const float* flow, float* out, int B, int C, int Hs, int Ws, int H, int W,
+                            long flow_bstride, int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream);
+int arflow_warp_nearest_bwd(const float* gout, const float* flow, float* gsrc, int B, int C, int Hs, int Ws, int H, int W,
+                            long flow_bstride, int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream);
+/* SSIM(x, y, md) distance map of losses/loss_blocks.py:65-84 for any window (2md+1)^2, 1 <= md <= 16:
+ * out [B,C,H-2md,W-2md]; arflow_ssim_bwd gives d(sum gmap*out)/dx (call with x and y swapped for d/dy: SSIM is
+ * symmetric).  (md = 1 fused with the L1 term and the mask sums is arflow_photo_fwd/bwd.) */
+int arflow_ssim_fwd(const float* x, const float* y, float* out, int B, int C, int H, int W, int md, arflow_stream_t stream);
+int arflow_ssim_bwd(const float* x, const float* y, const float* gmap, float* gx, int B, int C, int H, int W, int md,
+                    arflow_stream_t stream);
+/* arflow_census_fwd / arflow_census_bwd accept 1 <= radius <= 16 (TernaryLoss(max_distance), census_loss(patch_size));
+ * radius <= 3 runs the tiled kernels. */
+/* Correlation with the CUDA extension's full parameter set (correlation_cuda.cc:10-16, correlation_cuda_kernel.cu:41-114):
+ *   out[n, tc, oy, ox] = 1/(K^2 C) sum_{j,i in kernel} sum_c p1[c, y1+j, x1+i] * p2[c, y1+j+tj*s2, x1+i+ti*s2],
+ *   p = input zero-padded by pad_size, y1 = oy*stride1 + max_disp, tc = (tj+dr)*(2dr+1)+(ti+dr), dr = max_disp/stride2;
+ *   output dims as correlation_cuda.cc:31-34 (arflow_corr_general_out_size).  kernel_size odd.
+ * arflow_corr_general_bwd is the exact gradient of that forward (the extension's own backward bounds its window with
+ * floor divisions, correlation_cuda_kernel.cu:148-151, and over-counts taps when stride1 > 1).
+ * (pad_size = max_disp, kernel_size = stride1 = stride2 = 1 is arflow_corr_fwd/bwd.) */
+int arflow_corr_general_out_size(int H, int W, int pad_size, int kernel_size, int max_disp, int stride1, int stride2,
+                                 int* out_channels, int* out_h, int* out_w);
+int arflow_corr_general_fwd(const float* x1, const float* x2, float* out, int B, int C, int H, int W, int pad_size,
+                            int kernel_size, int max_disp, int stride1, int stride2, arflow_stream_t stream);
+int arflow_corr_general_bwd(const float* gout, const float* x1, const float* x2, float* gx1, float* gx2, int B, int C, int H,
+                            int W, int pad_size, int kernel_size, int max_disp, int stride1, int stride2,
+                            arflow_stream_t stream);
+
 /* ---- opt-in bf16 STORAGE of the features ----------------------------------------
  * The reference's native correlation dispatches half-precision tensors as well (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
  * correlation_cuda_kernel.cu:352,369).  Here: x1 / x2 / src hold bf16 bit patterns (uint16), every product is

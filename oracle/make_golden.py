@@ -305,6 +305,46 @@ def gen_examples():
     save('examples', **out)
 
 
+def gen_general():
+    """The parameter values no shipped config uses but the reference's functions accept: flow_warp(mode='nearest')
+    (utils/warp_utils.py:83-90), SSIM(md=2) (losses/loss_blocks.py:65-84), TernaryLoss(max_distance=4 / 5)
+    (losses/loss_blocks.py:12-62) -- reference outputs and autograd gradients."""
+    from utils import warp_utils
+    from losses import loss_blocks
+    rng = torch.Generator().manual_seed(4321)
+    out = {}
+    wcases = []
+    for k, (B, C, H, W, sc) in enumerate([(2, 3, 9, 13, 3.0), (1, 5, 16, 12, 6.0)]):
+        wcases.append(('w%d' % k, torch.randn(B, C, H, W, generator=rng), sc * torch.randn(B, 2, H, W, generator=rng),
+                       torch.randn(B, C, H, W, generator=rng)))
+    for name, x, flow, g in wcases:
+        out.update({name + '_x': x, name + '_flow': flow, name + '_g': g})
+        for pad in ('zeros', 'border'):
+            for ac in (True, False):
+                xx = x.clone().requires_grad_(True)
+                y = warp_utils.flow_warp(xx, flow, pad=pad, mode='nearest', align_corners=ac)
+                gx, = grads(y, [xx], g)
+                tag = '%s_%s_%d' % (name, pad, int(ac))
+                out.update({tag + '_y': y, tag + '_gx': gx})
+    out['wnames'] = np.array([c[0] for c in wcases])
+    im1, im2 = torch.rand(2, 3, 18, 23, generator=rng), torch.rand(2, 3, 18, 23, generator=rng)
+    out.update({'im1': im1, 'im2': im2})
+    for md in (2, 3):
+        a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
+        y = loss_blocks.SSIM(a, b, md=md)
+        g = torch.randn(y.shape, generator=rng)
+        ga, gb = grads(y, [a, b], g)
+        out.update({'ssim%d' % md: y, 'ssim%d_g' % md: g, 'ssim%d_ga' % md: ga, 'ssim%d_gb' % md: gb})
+    for md, sd in ((4, True), (5, False)):
+        a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
+        dist, mask = loss_blocks.TernaryLoss(a, b, max_distance=md, sum_dist=sd)
+        g = torch.randn(dist.shape, generator=rng)
+        ga, gb = grads(dist, [a, b], g)
+        tag = 'tern%d_%d' % (md, int(sd))
+        out.update({tag + '_dist': dist, tag + '_mask': mask, tag + '_g': g, tag + '_ga': ga, tag + '_gb': gb})
+    save('general', **out)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='all')
@@ -323,3 +363,5 @@ if __name__ == '__main__':
             gen_models()
         if args.only in ('all', 'examples'):
             gen_examples()
+        if args.only in ('all', 'general'):
+            gen_general()

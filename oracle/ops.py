@@ -114,6 +114,23 @@ def sample_bilinear(src, ix, iy, pad='zeros'):
     return out
 
 
+def sample_nearest(src, ix, iy, pad='zeros'):
+    """torch's ``grid_sample(mode='nearest')`` after un-normalisation (ATen/native/cpu/GridSamplerKernel.cpp /
+    GridSampler.cpp nearest branch): border padding clips the coordinate first, the index is
+    ``nearbyint`` (round half to even), out-of-range indices give zero.  No gradient w.r.t. the coordinates."""
+    B, C, H, W = src.shape
+    ix, iy = ix.detach(), iy.detach()
+    if pad == 'border':
+        ix, iy = ix.clamp(0, W - 1), iy.clamp(0, H - 1)
+    elif pad != 'zeros':
+        raise NotImplementedError(pad)
+    xi, yi = torch.round(ix), torch.round(iy)  # torch.round rounds half to even, like nearbyint
+    ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+    idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).long().reshape(B, 1, -1)
+    v = src.reshape(B, C, H * W).gather(2, idx.expand(B, C, idx.shape[-1])).reshape((B, C) + tuple(ix.shape[1:]))
+    return v * ok.unsqueeze(1).to(src.dtype)
+
+
 # --------------------------------------------------------------------------------------
 # a4  flow_warp (ARFlow)
 # --------------------------------------------------------------------------------------
@@ -125,7 +142,7 @@ def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True):
     this is reproduced, not fixed.  The normalise -> un-normalise round trip is kept in the
     working precision exactly as the reference + grid_sample perform it.
     """
-    if mode != 'bilinear':
+    if mode not in ('bilinear', 'nearest'):
         raise NotImplementedError(mode)
     B, _, H, W = flow.shape
     xs, ys = _pixel_grid(B, H, W, flow)
@@ -133,6 +150,8 @@ def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True):
     gy = 2.0 * (ys + flow[:, 1]) / (H - 1) - 1.0
     ix = _unnormalize(gx, x.shape[3], align_corners)
     iy = _unnormalize(gy, x.shape[2], align_corners)
+    if mode == 'nearest':
+        return sample_nearest(x, ix, iy, pad)
     return sample_bilinear(x, ix, iy, pad)
 
 
@@ -451,3 +470,38 @@ def normalize_features_uflow(feature_list, normalize=True, center=True,
     if normalize:
         feature_list = [f / s for f, s in zip(feature_list, stds)]
     return feature_list
+
+
+# --------------------------------------------------------------------------------------
+# a3  correlation with the CUDA extension's full parameter set
+# --------------------------------------------------------------------------------------
+def correlation_general(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """Forward of models/correlation_package/correlation_cuda_kernel.cu:41-114 with the output geometry of
+    correlation_cuda.cc:19-34, restated on NCHW tensors (differentiable: torch autograd of this expression is the
+    gradient).  PARITY UNPINNED for non-default parameters: the CUDA extension cannot be built here (no nvcc) and no
+    caller in the reference passes anything but (pad=d, kernel=1, stride1=stride2=1), which IS pinned through
+    models/correlation_native.py (``correlation`` above; tests compare the two on the default)."""
+    B, C, H, W = x1.shape
+    kr = (kernel_size - 1) // 2
+    dr = max_displacement // stride2
+    border = kr + max_displacement
+    ph, pw = H + 2 * pad_size, W + 2 * pad_size
+    ho = -(-(ph - 2 * border) // stride1)
+    wo = -(-(pw - 2 * border) // stride1)
+    # pad generously so that every index the loops touch exists (the kernel reads inside its padded buffers)
+    ext = max_displacement + kr + dr * stride2 + stride1
+    p1 = F.pad(x1, [pad_size + ext] * 4)
+    p2 = F.pad(x2, [pad_size + ext] * 4)
+    ys = torch.arange(ho) * stride1 + max_displacement + ext
+    xs = torch.arange(wo) * stride1 + max_displacement + ext
+    outs = []
+    for tj in range(-dr, dr + 1):
+        for ti in range(-dr, dr + 1):
+            acc = 0.
+            for j in range(-kr, kr + 1):
+                for i in range(-kr, kr + 1):
+                    a = p1[:, :, (ys + j)[:, None], (xs + i)[None, :]]
+                    b = p2[:, :, (ys + j + tj * stride2)[:, None], (xs + i + ti * stride2)[None, :]]
+                    acc = acc + (a * b).sum(1)
+            outs.append(acc / float(kernel_size * kernel_size * C))
+    return torch.stack(outs, 1)

@@ -60,7 +60,7 @@ def test_argument_errors_without_gpu(lib):
     assert lib.arflow_corr_sign_planes(32, 160, 4) == 3 and lib.arflow_corr_sign_planes(32, 10, 4) == 0
     assert lib.arflow_warp_fwd(one, one, one, None, 1, 1, 4, 4, 4, 4, 32, 7, 1, 0, None) == -1003
     assert lib.arflow_warp_fwd(one, one, one, None, 1, 1, 4, 4, 4, 4, 3, 0, 1, 0, None) == -1002
-    assert lib.arflow_census_fwd(one, one, None, one, None, None, 1, 8, 8, 4, None) == -1003
+    assert lib.arflow_census_fwd(one, one, None, one, None, None, 1, 8, 8, 17, None) == -1003  # radius 1..16
     assert lib.arflow_down4(one, one, 1, 6, 8, None) == -1002
     assert b'NULL' in lib.arflow_strerror(-1001)
 

@@ -725,3 +725,72 @@ def test_bf16_storage_warp(AF, oracle, cfg):
     assert gx.dtype == torch.float32
     assert_close(gx, rgx, 1e-5 * max(1.0, float(rgx.abs().max())), 1e-4, 'bf16-storage warp gsrc')
     assert_close(gf, rgf, 1e-5 * (C ** 0.5) * float(x.abs().max()) * 4, 2e-4, 'bf16-storage warp gflow')
+
+
+def test_general_parameter_space_golden(golden):
+    """The parameter values no shipped config uses, against vectors frozen from the REFERENCE
+    (tests/golden/general.npz): flow_warp(mode='nearest') for both paddings / align_corners with d/d source;
+    SSIM(md=2,3) and TernaryLoss(max_distance=4,5) with both gradients."""
+    from arflow_amd import loss_blocks as LB
+    from arflow_amd.warp_utils import flow_warp
+    g = golden('general')
+    for name in g['wnames']:
+        for pad in ('zeros', 'border'):
+            for ac in (True, False):
+                tag = '%s_%s_%d' % (name, pad, int(ac))
+                x = cu(g[name + '_x']).requires_grad_(True)
+                fl = cu(g[name + '_flow']).requires_grad_(True)
+                y = flow_warp(x, fl, pad=pad, mode='nearest', align_corners=ac)
+                # a coordinate within rounding of x.5 may pick the other neighbour: compare where it is not
+                assert float((y.cpu() != g[tag + '_y']).float().mean()) <= 0.01, tag
+                gx, gf = torch.autograd.grad(y, [x, fl], cu(g[name + '_g']))
+                assert float((gx.cpu() - g[tag + '_gx']).abs().gt(1e-5).float().mean()) <= 0.02, tag + ' gx'
+                assert float(gf.abs().max()) == 0.0  # grid_sample's nearest mode has no grid gradient
+    im1, im2 = cu(g['im1']), cu(g['im2'])
+    for md in (2, 3):
+        a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
+        y = LB.SSIM(a, b, md=md)
+        assert_close(y, g['ssim%d' % md], 5e-5, 1e-5, 'ssim md=%d' % md)
+        ga, gb = torch.autograd.grad(y, [a, b], cu(g['ssim%d_g' % md]))
+        for got_, key in ((ga, 'ssim%d_ga' % md), (gb, 'ssim%d_gb' % md)):
+            ref_ = g[key]
+            assert_close(got_, ref_, 2e-4 * float(ref_.abs().max()), 1e-3, key)
+    for md, sd in ((4, True), (5, False)):
+        tag = 'tern%d_%d' % (md, int(sd))
+        a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
+        dist, tm = LB.TernaryLoss(a, b, md, sd)
+        assert_close(dist, g[tag + '_dist'], 2e-5, 2e-5, tag)
+        assert_close(tm, g[tag + '_mask'], 0, 0, tag + ' mask')
+        ga, gb = torch.autograd.grad(dist, [a, b], cu(g[tag + '_g']))
+        for got_, key in ((ga, '_ga'), (gb, '_gb')):
+            ref_ = g[tag + key]
+            assert_close(got_, ref_, 1e-4 * float(ref_.abs().max()), 2e-4, tag + key)
+
+
+@pytest.mark.parametrize('cfg', [(4, 1, 4, 1, 1), (3, 3, 2, 2, 2), (20, 1, 20, 1, 2), (2, 1, 4, 1, 1), (5, 3, 4, 2, 1)],
+                         ids=lambda c: 'pad%d_k%d_d%d_s%d_%d' % c)
+def test_general_correlation_parameters(oracle, cfg):
+    """Correlation(pad_size, kernel_size, max_displacement, stride1, stride2) with the CUDA extension's semantics
+    (correlation_cuda.cc:10-34, correlation_cuda_kernel.cu:41-114) against oracle.correlation_general and ITS autograd
+    gradient.  Parity unpinned beyond the default parameter set (the extension cannot be built here); the default set
+    must equal the tuned kernels and the pinned correlation_native restatement."""
+    from arflow_amd.correlation import Correlation
+    pad, k, d, s1, s2 = cfg
+    gen = torch.Generator().manual_seed(sum(cfg))
+    B, C, H, W = 2, 6, 26, 31
+    x1, x2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    ref = oracle.correlation_general(a, b, pad, k, d, s1, s2)
+    go = torch.randn(ref.shape, generator=gen)
+    r1, r2 = torch.autograd.grad(ref, [a, b], go)
+    m = Correlation(pad_size=pad, kernel_size=k, max_displacement=d, stride1=s1, stride2=s2, corr_multiply=1)
+    ac, bc = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
+    y = m(ac, bc)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    assert_close(y, ref, 1e-6, 1e-5, 'general corr fwd')
+    g1, g2 = torch.autograd.grad(y, [ac, bc], cu(go))
+    assert_close(g1, r1, 5e-6, 1e-5, 'general corr gx1')
+    assert_close(g2, r2, 5e-6, 1e-5, 'general corr gx2')
+    if cfg == (4, 1, 4, 1, 1):
+        assert m.general is None  # the default set runs the tuned kernels
+        assert_close(y, oracle.correlation(x1, x2, 4), 1e-6, 1e-5, 'default == correlation_native')

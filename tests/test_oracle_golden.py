@@ -219,3 +219,37 @@ def test_correlation_gradcheck_float64():
     x1 = torch.randn(1, 3, 5, 6, dtype=torch.float64, requires_grad=True)
     x2 = torch.randn(1, 3, 5, 6, dtype=torch.float64, requires_grad=True)
     assert torch.autograd.gradcheck(lambda a, b: ops.correlation(a, b, 2), (x1, x2), eps=1e-6, atol=1e-8)
+
+
+def test_general_parameter_space_oracle_vs_reference(golden):
+    """Parameter values no shipped config uses (tests/golden/general.npz, frozen from the reference):
+    flow_warp(mode='nearest'), SSIM(md=2,3), TernaryLoss(max_distance=4,5)."""
+    from oracle import ops as O
+    g = golden('general')
+    for name in g['wnames']:
+        for pad in ('zeros', 'border'):
+            for ac in (True, False):
+                tag = '%s_%s_%d' % (name, pad, int(ac))
+                x = g[name + '_x'].requires_grad_(True)
+                y = O.flow_warp(x, g[name + '_flow'], pad=pad, mode='nearest', align_corners=ac)
+                assert_close(y, g[tag + '_y'], 0, 0, tag)
+                gx, = torch.autograd.grad(y, [x], g[name + '_g'])
+                assert_close(gx, g[tag + '_gx'], 1e-6, 1e-6, tag + ' gx')
+    for md in (2, 3):
+        assert_close(O.ssim(g['im1'], g['im2'], md), g['ssim%d' % md], 1e-6, 1e-6, 'ssim md')
+    for md, sd in ((4, True), (5, False)):
+        tag = 'tern%d_%d' % (md, int(sd))
+        d, m = O.ternary_loss(g['im1'], g['im2'], md, sd)
+        assert_close(d, g[tag + '_dist'], 1e-6, 1e-6, tag)
+        assert_close(m, g[tag + '_mask'], 0, 0, tag + ' mask')
+
+
+def test_general_correlation_oracle_reduces_to_the_pinned_default():
+    """oracle.correlation_general (restated from correlation_cuda_kernel.cu:41-114; parity unpinned for non-default
+    parameters) with (pad=d, kernel=1, strides 1) equals the pinned correlation_native restatement."""
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(3)
+    x1, x2 = torch.randn(2, 5, 9, 11, generator=gen), torch.randn(2, 5, 9, 11, generator=gen)
+    assert_close(O.correlation_general(x1, x2, 4, 1, 4, 1, 1), O.correlation(x1, x2, 4), 1e-7, 1e-6, 'default')
+    y = O.correlation_general(x1, x2, 3, 3, 2, 2, 2)  # FlowNetC-like: pad 3, 3x3 kernel, d 2, strides 2
+    assert y.shape == (2, 9, 5, 6)  # ceil((9+6-6)/2), ceil((11+6-6)/2); (2*(2//2)+1)^2 channels
