@@ -17,9 +17,10 @@
 namespace {
 
 constexpr int NT = 256, VPT = 16;  // floats per thread per tensor and trip (4 float4)
-// Partial sums meet in NSLOT rows of 4 doubles per sample (row = workgroup % NSLOT): ~120 workgroups adding
-// into ONE address per sample serialise at the L2 (measured 30 us for a 63 MB pass); the readers add the rows.
-constexpr int NSLOT = ARFLOW_FEATNORM_SLOTS;
+// Partial sums: every workgroup of the reduction pass STORES its 4 doubles into its own row of `acc`
+// ([B][rows][4], rows = its grid.x <= 2048/B + 1), the apply pass adds a sample's rows (one per lane, wave-reduced).
+// No zero-fill and no atomics (round 1 added into 8 slotted rows per sample after a hipMemsetAsync -- a separate
+// ~4 us GPU operation per call; ~120 workgroups adding into ONE address per sample had serialised at the L2).
 
 // sum over the block of NV doubles per thread; result in thread 0
 template <int NV, int NTH = NT>
@@ -51,12 +52,24 @@ struct Moments {
 
 // (sum x1, sum x1^2, sum x2, sum x2^2) -> the sample's statistics
 __device__ __forceinline__ Moments moments_from_totals(const double (&a)[4], long n, int mode);
-__device__ __forceinline__ Moments moments_of(const double* rows, long n, int mode) {
-  double a[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int r = 0; r < NSLOT; ++r) {
+// sum of the first NV entries of `nrows` rows of 4 doubles: one row per lane, then a wave reduction (every lane gets it)
+template <int NV>
+__device__ __forceinline__ void sum_rows(const double* rows, int nrows, double (&a)[NV]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] += rows[4 * r + k];
+  for (int k = 0; k < NV; ++k) a[k] = 0.0;
+  for (int r = threadIdx.x & 63; r < nrows; r += 64) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] += rows[4 * r + k];
   }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_xor(a[k], off, 64);
+  }
+}
+__device__ __forceinline__ Moments moments_of(const double* rows, int nrows, long n, int mode) {
+  double a[4];
+  sum_rows<4>(rows, nrows, a);
   return moments_from_totals(a, n, mode);
 }
 __device__ __forceinline__ Moments moments_from_totals(const double (&a)[4], long n, int mode) {
@@ -110,17 +123,17 @@ __global__ __launch_bounds__(NT) void moment_kernel(const float* __restrict__ x1
   block_sum_f64<4>(s, scratch);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(acc + 4 * (NSLOT * b + blockIdx.x % NSLOT) + k, s[k]);
+    for (int k = 0; k < 4; ++k) acc[4 * ((long)b * gridDim.x + blockIdx.x) + k] = s[k];
   }
 }
 
 // y_i = (x_i - mu) / std; block (0, b) records (m1, m2, mu, std) for the backward.
 __global__ __launch_bounds__(NT) void apply_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                    float* __restrict__ y1, float* __restrict__ y2,
-                                                   const double* __restrict__ acc, float* __restrict__ stats, long n,
-                                                   int mode) {
+                                                   const double* __restrict__ acc, int nrows, float* __restrict__ stats,
+                                                   long n, int mode) {
   const int b = blockIdx.y;
-  const Moments m = moments_of(acc + 4 * NSLOT * b, n, mode);
+  const Moments m = moments_of(acc + 4L * nrows * b, nrows, n, mode);
   const float sd = sqrtf(m.var + 1e-16f);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float* st = stats + 4 * b;
@@ -178,8 +191,8 @@ __global__ __launch_bounds__(NT) void bwd_sum_kernel(const float* __restrict__ g
   }
   block_sum_f64<2>(s, scratch);
   if (threadIdx.x == 0) {
-    atomicAdd(acc + 4 * (NSLOT * b + blockIdx.x % NSLOT), s[0]);
-    atomicAdd(acc + 4 * (NSLOT * b + blockIdx.x % NSLOT) + 1, s[1]);
+    acc[4 * ((long)b * gridDim.x + blockIdx.x)] = s[0];
+    acc[4 * ((long)b * gridDim.x + blockIdx.x) + 1] = s[1];
   }
 }
 
@@ -189,13 +202,14 @@ __global__ __launch_bounds__(NT) void bwd_sum_kernel(const float* __restrict__ g
 __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                        const float* __restrict__ x1, const float* __restrict__ x2,
                                                        const float* __restrict__ stats, const double* __restrict__ acc,
-                                                       float* __restrict__ d1, float* __restrict__ d2, long n,
+                                                       int nrows, float* __restrict__ d1, float* __restrict__ d2, long n,
                                                        int mode) {
   const int b = blockIdx.y;
   const float* st = stats + 4 * b;
   const double r = 1.0 / (double)st[3];
-  double G = 0.0, Q = 0.0;
-  for (int r = 0; r < NSLOT; ++r) G += acc[4 * (NSLOT * b + r)], Q += acc[4 * (NSLOT * b + r) + 1];
+  double gq[2];
+  sum_rows<2>(acc + 4L * nrows * b, nrows, gq);
+  const double G = gq[0], Q = gq[1];
   const double dn = (double)n;
   const float rf = (float)r;
   const float cg = (float)(r * G / (2.0 * dn));
@@ -366,12 +380,11 @@ extern "C" int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, 
     hipLaunchKernelGGL(fwd_small_kernel, dim3(B), dim3(NTS), 0, st, x1, x2, y1, y2, stats, n, mode);
     return af_launch_status();
   }
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 4 * NSLOT * (size_t)B, st);
-  if (e != hipSuccess) return af_hip_status(e);
-  hipLaunchKernelGGL(moment_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, x1, x2, acc, n);
+  const unsigned rows = blocks_per_sample(B, n, NT * VPT);  // rows * B <= 2048 + B: fits ARFLOW_FEATNORM_ACC_DOUBLES(B)
+  hipLaunchKernelGGL(moment_kernel, dim3(rows, B), dim3(NT), 0, st, x1, x2, acc, n);
   AF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, x1, x2, y1, y2, acc, stats, n,
-                     mode);
+  hipLaunchKernelGGL(apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, x1, x2, y1, y2, acc, (int)rows,
+                     stats, n, mode);
   return af_launch_status();
 }
 
@@ -393,12 +406,10 @@ extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float
     hipLaunchKernelGGL(bwd_small_kernel, dim3(B), dim3(NTS), 0, st, g1, g2, x1, x2, stats, gx1, gx2, n, mode);
     return af_launch_status();
   }
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 4 * NSLOT * (size_t)B, st);
-  if (e != hipSuccess) return af_hip_status(e);
-  hipLaunchKernelGGL(bwd_sum_kernel, dim3(blocks_per_sample(B, n, NT * VPT), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
-                     n);
+  const unsigned rows = blocks_per_sample(B, n, NT * VPT);
+  hipLaunchKernelGGL(bwd_sum_kernel, dim3(rows, B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc, n);
   AF_LAUNCH_CHECK();
   hipLaunchKernelGGL(bwd_apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
-                     gx1, gx2, n, mode);
+                     (int)rows, gx1, gx2, n, mode);
   return af_launch_status();
 }

@@ -327,7 +327,8 @@ def correlation_concat(x1, x2, before=(), after=(), max_displacement=4, negative
 
 # ------------------------------------------------------------------------------------------------
 FEATNORM = {'joint': 0, 'avg': 1}
-FEATNORM_SLOTS = 8  # ARFLOW_FEATNORM_SLOTS
+def _featnorm_acc(B, device):  # ARFLOW_FEATNORM_ACC_DOUBLES(B)
+    return torch.empty(4 * (2048 + B), device=device, dtype=torch.float64)
 
 
 class FeatureNormFunction(torch.autograd.Function):
@@ -344,7 +345,7 @@ class FeatureNormFunction(torch.autograd.Function):
         B = x1.shape[0]
         n = x1[0].numel()
         y1, y2 = torch.empty_like(x1), torch.empty_like(x2)
-        acc = torch.empty(4 * FEATNORM_SLOTS * B, device=x1.device, dtype=torch.float64)
+        acc = _featnorm_acc(B, x1.device)
         stats = torch.empty(B, 4, device=x1.device, dtype=torch.float32)
         with torch.cuda.device_of(x1):
             _call('arflow_featnorm_fwd', _p(x1), _p(x2), _p(y1), _p(y2), _p(acc), _p(stats), B, n, mode, _stream(),
@@ -361,7 +362,7 @@ class FeatureNormFunction(torch.autograd.Function):
         g1, g2 = g1.contiguous(), g2.contiguous()
         d1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
         d2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
-        acc = torch.empty(4 * FEATNORM_SLOTS * B, device=x1.device, dtype=torch.float64)
+        acc = _featnorm_acc(B, x1.device)
         with torch.cuda.device_of(x1):
             _call('arflow_featnorm_bwd', _p(g1), _p(g2), _p(x1), _p(x2), _p(stats), _p(acc), _p(d1), _p(d2), B, n,
                   ctx.mode, _stream(), key=(B, n))

@@ -113,13 +113,13 @@ int arflow_corr_bwd_strided(const float* gout, long gout_bstride, const float* o
  *                          channel-concatenated pair, unbiased variance over 2n - 1)
  *   ARFLOW_FEATNORM_AVG    normalize_features of models/uflow_model.py:8-50 as PWCFlow calls it (:167-172):
  *                          per-tensor mean / unbiased variance over (C,H,W), averaged across the two images
- * x1,x2,y1,y2: [B, n] contiguous (n = C*H*W >= 2).  acc: 4*ARFLOW_FEATNORM_SLOTS*B doubles of scratch
- * (zero-filled here).
+ * x1,x2,y1,y2: [B, n] contiguous (n = C*H*W >= 2).  acc: ARFLOW_FEATNORM_ACC_DOUBLES(B) doubles of scratch
+ * (need not be initialised: every workgroup of the reduction pass stores its partial sums into its own row).
  * stats: [B,4] floats written by the forward (m1, m2, mu, std) and read by the backward.
  * Backward: gx1 / gx2 (nullable) = gradients w.r.t. x1 / x2 given g1, g2 = gradients w.r.t. y1, y2. */
 #define ARFLOW_FEATNORM_JOINT 0
 #define ARFLOW_FEATNORM_AVG 1
-#define ARFLOW_FEATNORM_SLOTS 8
+#define ARFLOW_FEATNORM_ACC_DOUBLES(B) (4 * (2048 + (B)))
 int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, float* y2, double* acc, float* stats,
                         int B, long n, int mode, arflow_stream_t stream);
 int arflow_featnorm_bwd(const float* g1, const float* g2, const float* x1, const float* x2,

@@ -88,7 +88,7 @@ def main():
             rec('arflow_warp_bwd', (B2, C, h, w, True), timeit(lambda: lib.arflow_warp_bwd(p(x1), p(x2), p(fl), p(g2), p(gfl), B2, C, h, w, h, w, 2 * h * w, 0, 1, 0, s), args.iters))
         if want('featnorm'):
             n = C * h * w
-            acc = torch.empty(4 * 8 * B2, device=dev, dtype=torch.float64)
+            acc = torch.empty(4 * (2048 + B2), device=dev, dtype=torch.float64)
             stt = torch.empty(B2, 4, device=dev)
             rec('arflow_featnorm_fwd', (B2, n), timeit(lambda: lib.arflow_featnorm_fwd(p(x1), p(x2), p(g1), p(g2), p(acc), p(stt), B2, n, 0, s), args.iters))
             rec('arflow_featnorm_bwd', (B2, n), timeit(lambda: lib.arflow_featnorm_bwd(p(x1), p(x2), p(x1), p(x2), p(stt), p(acc), p(g1), p(g2), B2, n, 0, s), args.iters))
