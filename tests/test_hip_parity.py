@@ -185,8 +185,12 @@ def test_correlation_module_signature(AF):
     m = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
     x = torch.randn(1, 8, 12, 20, device='cuda')
     assert m(x, x).shape == (1, 81, 12, 20)
-    with pytest.raises(NotImplementedError):
-        Correlation(pad_size=3, kernel_size=3, max_displacement=20, stride1=1, stride2=2)
+    # the CUDA extension's other parameters (FlowNetC's set) run the general kernels with its output geometry
+    # (correlation_cuda.cc:31-34): ((20/2)*2+1)^2 channels, ceil((12 + 40 - 40) / 1) x ceil((20 + 40 - 40) / 1)
+    g = Correlation(pad_size=20, kernel_size=1, max_displacement=20, stride1=1, stride2=2)
+    assert g(x, x).shape == (1, 441, 12, 20)
+    with pytest.raises(ValueError):
+        Correlation(pad_size=3, kernel_size=2, max_displacement=4)  # even kernel sizes do not exist in the extension
     with pytest.raises(ValueError):
         compute_cost_volume(x[:, :, :4], x[:, :, :4], 4)
 
