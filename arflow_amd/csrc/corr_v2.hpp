@@ -203,26 +203,31 @@ __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_ker
     }
   }
 
-  if (G > 1) {  // groups 1 .. G-1 hand their partial sums to group 0 through the rings, one row shift at a time
+  if (G > 1) {  // groups 1 .. G-1 hand their partial sums to group 0 through the rings
+    // One row shift at a time, ALL foreign groups at once, each into its own region (3 waves x 9 columns x 64 lanes
+    // x 16 B = 27.6 KB per group: 3 groups fit the 4 rings): 2 barriers per row shift = 6 in all.  (Round 1 handed
+    // over one group at a time: 18 barriers of a 768-thread workgroup, ~6 us of the ~13 us a coarse level takes.)
+    static_assert((G - 1) * NW * N * 64 * PX <= G * RING, "the hand-over regions live in the rings");
     f32x4* xch = reinterpret_cast<f32x4*>(lds_all) + (wave * N) * 64 + lane;
-#pragma unroll 1
-    for (int g = 1; g < G; ++g) {
+    constexpr int REGION = NW * N * 64;  // float4 per foreign group
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        __syncthreads();  // all FMAs done with the rings / group 0 has consumed the previous hand-over
-        if (grp == g) {
+    for (int k = 0; k < 3; ++k) {
+      __syncthreads();  // all FMAs done with the rings / group 0 has consumed the previous row shift
+      if (grp != 0) {
 #pragma unroll
-          for (int j = 0; j < N; ++j) {
-            f32x4 t;
-            t.x = acc[k][j][0], t.y = acc[k][j][1], t.z = acc[k][j][2], t.w = acc[k][j][3];
-            xch[j * 64] = t;
-          }
+        for (int j = 0; j < N; ++j) {
+          f32x4 t;
+          t.x = acc[k][j][0], t.y = acc[k][j][1], t.z = acc[k][j][2], t.w = acc[k][j][3];
+          xch[(grp - 1) * REGION + j * 64] = t;
         }
-        __syncthreads();
-        if (grp == 0) {
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll 1
+        for (int g = 1; g < G; ++g) {
 #pragma unroll
           for (int j = 0; j < N; ++j) {
-            const f32x4 t = xch[j * 64];
+            const f32x4 t = xch[(g - 1) * REGION + j * 64];
             acc[k][j][0] += t.x, acc[k][j][1] += t.y, acc[k][j][2] += t.z, acc[k][j][3] += t.w;
           }
         }
