@@ -3,7 +3,7 @@
 #include <atomic>
 #include <cstdio>
 
-extern "C" int arflow_abi_version(void) { return 8; }
+extern "C" int arflow_abi_version(void) { return 9; }
 
 // A HIP error that was already pending on the calling thread when an entry point was entered (left behind by
 // the framework or by an earlier, unchecked call).  Kept, not dropped: first one is reported once on stderr.
@@ -33,3 +33,13 @@ extern "C" const char* arflow_strerror(int code) {
   if (code <= ARFLOW_ELAUNCH_BASE) return hipGetErrorString((hipError_t)(ARFLOW_ELAUNCH_BASE - code));
   return "unknown arflow error code";
 }
+
+// Rows of every `sums` buffer: at least the workgroup count of any reduction kernel on a [B, *, H, W] problem -- the
+// 8 x 32 pixel tiling rounded up to 8 (af_grid_for_tiles; the 16 x 64 tilings need fewer), and the one-thread-per-pixel
+// kernels' ceil(W/256) x H x B grid.
+int af_sums_rows(int B, int H, int W) {
+  const long a = 8L * (((long)af_cdiv(W, 32) * af_cdiv(H, 8) * B + 7) / 8);
+  const long b = (long)af_cdiv(W, 256) * H * B;
+  return (int)(a > b ? a : b);
+}
+extern "C" int arflow_sums_rows(int B, int H, int W) { return (B > 0 && H > 0 && W > 0) ? af_sums_rows(B, H, W) : ARFLOW_ESHAPE; }

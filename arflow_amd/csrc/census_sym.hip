@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT, 2) void kernel(const float* __restrict__ gray_a
                                             const float* __restrict__ occ_small,  // fwd
                                             float* __restrict__ mask_out,         // fwd
                                             float* __restrict__ dham,             // fwd: out, bwd: in
-                                            float* __restrict__ sums,             // fwd
+                                            float* __restrict__ sums, int nrows,  // fwd
                                             const float* __restrict__ scale,      // bwd
                                             float* __restrict__ gflow,            // bwd
                                             int nimg, int H, int W, int strip_h) {
@@ -243,7 +243,10 @@ __global__ __launch_bounds__(NT, 2) void kernel(const float* __restrict__ gray_a
   __shared__ float red[2 * (NT / 64)];
   const int nsx = (W + SW - 1) / SW, nsy = (H + strip_h - 1) / strip_h;
   int stx, sty, b;
-  if (!af_tile_of_block(nsx, nsy, nimg, stx, sty, b)) return;
+  if (!af_tile_of_block(nsx, nsy, nimg, stx, sty, b)) {
+    if (!BWD && threadIdx.x == 0) af_store_partial(sums, nrows, 0.f, 0.f, 0.f);  // padding workgroup: its row must be defined
+    return;
+  }
   const int sx0 = stx * SW, sy0 = sty * strip_h, sy1 = min(sy0 + strip_h, H);
   const long cs = (long)H * W;
   const float* fl = flow + b * fbs;
@@ -344,11 +347,7 @@ __global__ __launch_bounds__(NT, 2) void kernel(const float* __restrict__ gray_a
   }
   if (!BWD) {
     af_block_sum<2>(part, red);
-    if (threadIdx.x == 0) {
-      float* slot = af_sum_slot(sums);
-      atomicAdd(slot, part[0]);
-      atomicAdd(slot + 1, part[1]);
-    }
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
   }
 }
 
@@ -365,14 +364,14 @@ static int census_sym_strip_h(int B, int H, int W, int R) {
 }
 
 int census_sym_fwd(const float* gray_a, const float* gray_b, const float* flow, long fbs, const float* occ_small,
-                   float* mask_out, float* dham, float* sums, int B, int H, int W, int radius, hipStream_t st) {
+                   float* mask_out, float* dham, float* sums, int nrows, int B, int H, int W, int radius, hipStream_t st) {
   namespace cs = census_sym;
   const int sh = census_sym_strip_h(B, H, W, radius);
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cs::SW) * af_cdiv(H, sh) * B));
   switch (radius) {
-    case 1: hipLaunchKernelGGL((cs::kernel<1, false>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, occ_small, mask_out, dham, sums, nullptr, nullptr, B, H, W, sh); break;
-    case 2: hipLaunchKernelGGL((cs::kernel<2, false>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, occ_small, mask_out, dham, sums, nullptr, nullptr, B, H, W, sh); break;
-    default: hipLaunchKernelGGL((cs::kernel<3, false>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, occ_small, mask_out, dham, sums, nullptr, nullptr, B, H, W, sh); break;
+    case 1: hipLaunchKernelGGL((cs::kernel<1, false>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, occ_small, mask_out, dham, sums, nrows, nullptr, nullptr, B, H, W, sh); break;
+    case 2: hipLaunchKernelGGL((cs::kernel<2, false>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, occ_small, mask_out, dham, sums, nrows, nullptr, nullptr, B, H, W, sh); break;
+    default: hipLaunchKernelGGL((cs::kernel<3, false>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, occ_small, mask_out, dham, sums, nrows, nullptr, nullptr, B, H, W, sh); break;
   }
   return af_launch_status();
 }
@@ -384,9 +383,9 @@ int census_sym_bwd(const float* gray_a, const float* gray_b, const float* flow, 
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cs::SW) * af_cdiv(H, sh) * B));
   float* dh = const_cast<float*>(dham);
   switch (radius) {
-    case 1: hipLaunchKernelGGL((cs::kernel<1, true>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, nullptr, nullptr, dh, nullptr, scale, gflow, B, H, W, sh); break;
-    case 2: hipLaunchKernelGGL((cs::kernel<2, true>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, nullptr, nullptr, dh, nullptr, scale, gflow, B, H, W, sh); break;
-    default: hipLaunchKernelGGL((cs::kernel<3, true>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, nullptr, nullptr, dh, nullptr, scale, gflow, B, H, W, sh); break;
+    case 1: hipLaunchKernelGGL((cs::kernel<1, true>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, nullptr, nullptr, dh, nullptr, 0, scale, gflow, B, H, W, sh); break;
+    case 2: hipLaunchKernelGGL((cs::kernel<2, true>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, nullptr, nullptr, dh, nullptr, 0, scale, gflow, B, H, W, sh); break;
+    default: hipLaunchKernelGGL((cs::kernel<3, true>), g, dim3(cs::NT), 0, st, gray_a, gray_b, flow, fbs, nullptr, nullptr, dh, nullptr, 0, scale, gflow, B, H, W, sh); break;
   }
   return af_launch_status();
 }

@@ -117,13 +117,16 @@ template <int R>
 __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ gray_a, const float* __restrict__ gray_b,
                                                  const float* __restrict__ flow, long fbs,
                                                  const float* __restrict__ occ_small, float* __restrict__ mask_out,
-                                                 float* __restrict__ dham_out, float* __restrict__ sums, int nimg,
-                                                 int H, int W) {
+                                                 float* __restrict__ dham_out, float* __restrict__ sums, int nrows,
+                                                 int nimg, int H, int W) {
   __shared__ __attribute__((aligned(16))) float ga[ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float gb[ROWS * PITCH];
   __shared__ float red[2 * (NT / 64)];
   int btx, bty, b;
-  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) return;
+  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) {
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, 0.f, 0.f, 0.f);  // padding workgroup: its row must be defined
+    return;
+  }
   const int ty0 = bty * TYH, tx0 = btx * TXW;
   const long cs = (long)H * W;
   const float* fl = flow + b * fbs;
@@ -183,11 +186,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ gray_
     *reinterpret_cast<float4*>(dham_out + (long)b * cs + o) = make_float4(dh[0], dh[1], dh[2], dh[3]);
   }
   af_block_sum<2>(part, red);
-  if (threadIdx.x == 0) {
-    float* slot = af_sum_slot(sums);
-    atomicAdd(slot, part[0]);
-    atomicAdd(slot + 1, part[1]);
-  }
+  if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
 }
 
 template <int R>
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(256) void down4_gray_kernel(const float* __restrict
 // of this file at the BASELINE shape (8x384x640: forward 76 us vs 58 us, backward 89 us vs 69 us), so
 // they are opt-in: ARFLOW_CENSUS_SYM=1 selects them (tests run both, tools/kbench.py times both).
 int census_sym_fwd(const float* gray_a, const float* gray_b, const float* flow, long fbs, const float* occ_small,
-                   float* mask_out, float* dham, float* sums, int B, int H, int W, int radius, hipStream_t st);
+                   float* mask_out, float* dham, float* sums, int nrows, int B, int H, int W, int radius, hipStream_t st);
 int census_sym_bwd(const float* gray_a, const float* gray_b, const float* flow, long fbs, const float* dham,
                    const float* scale, float* gflow, int B, int H, int W, int radius, hipStream_t st);
 static bool use_sym() {
@@ -346,15 +345,14 @@ extern "C" int arflow_census_warp_fwd(const float* gray_a, const float* gray_b, 
   AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
   AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
-  if (e != hipSuccess) return af_hip_status(e);
-  if (use_sym()) return census_sym_fwd(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, B, H, W, radius, st);
+  const int nrows = af_sums_rows(B, H, W);
+  if (use_sym()) return census_sym_fwd(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, radius, st);
   namespace cw = census_warp;
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B));
   switch (radius) {
-    case 1: hipLaunchKernelGGL(cw::fwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, B, H, W); break;
-    case 2: hipLaunchKernelGGL(cw::fwd_kernel<2>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, B, H, W); break;
-    default: hipLaunchKernelGGL(cw::fwd_kernel<3>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, B, H, W); break;
+    case 1: hipLaunchKernelGGL(cw::fwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W); break;
+    case 2: hipLaunchKernelGGL(cw::fwd_kernel<2>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W); break;
+    default: hipLaunchKernelGGL(cw::fwd_kernel<3>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W); break;
   }
   return af_launch_status();
 }

@@ -70,12 +70,19 @@ __device__ __forceinline__ void af_block_sum(float (&v)[NV], float* scratch) {
   }
 }
 
-// Row of the slotted `sums` buffer this workgroup adds into (see ARFLOW_NSLOT in the header).
-__device__ __forceinline__ float* af_sum_slot(float* sums) {
-  const unsigned s = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z + (blockIdx.x >> 6)) % ARFLOW_NSLOT;
-  return sums + s * ARFLOW_SLOT_STRIDE;
+// Reduction outputs ("sums"): every workgroup STORES its partial sums into its own row of ARFLOW_SUM_COLS floats
+// (row = linear workgroup id) and zero-fills the rows beyond the grid, so after the launch every one of the `nrows`
+// rows is defined and the caller adds them all -- no zero-fill launch, no atomics, and a result that does not depend
+// on the order workgroups finish in.  (Round 1: hipMemsetAsync + atomicAdd into 256 slotted rows -- the memset was
+// a separate ~4 us GPU operation in front of every reduction.)  nrows >= number of workgroups, host-checked.
+__device__ __forceinline__ void af_store_partial(float* __restrict__ sums, int nrows, float a, float b, float c) {
+  const int nwg = gridDim.x * gridDim.y * gridDim.z;
+  const int w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  *reinterpret_cast<float4*>(sums + (long)w * ARFLOW_SUM_COLS) = make_float4(a, b, c, 0.f);
+  for (int r = w + nwg; r < nrows; r += nwg)
+    *reinterpret_cast<float4*>(sums + (long)r * ARFLOW_SUM_COLS) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-#define AF_SUMS_BYTES (sizeof(float) * ARFLOW_NSLOT * ARFLOW_SLOT_STRIDE)
+int af_sums_rows(int B, int H, int W);  // api.hip: rows every `sums` buffer has (>= the grid of any reduction kernel)
 
 // XCD-aware workgroup -> tile map for 1-D grids of 2-D tiles.  Workgroups are dealt round-robin over the
 // 8 XCDs (private L2 each), so consecutive ids would spread neighbouring tiles -- which share halo rows

@@ -66,8 +66,8 @@ __device__ __forceinline__ float gray255_at(const float* __restrict__ im, int H,
 // same outputs as census4::fwd_kernel (photo.hip): ham and / or the fused census_loss pieces
 __global__ __launch_bounds__(256) void census_any_fwd_kernel(const float* __restrict__ im_a, const float* __restrict__ im_b,
                                                              const float* __restrict__ mask, float* __restrict__ ham_out,
-                                                             float* __restrict__ dham_out, float* __restrict__ sums, int H,
-                                                             int W, int R) {
+                                                             float* __restrict__ dham_out, float* __restrict__ sums, int nrows,
+                                                             int H, int W, int R) {
   __shared__ float red[2 * 4];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
   float part[2] = {0.f, 0.f};
@@ -95,11 +95,7 @@ __global__ __launch_bounds__(256) void census_any_fwd_kernel(const float* __rest
   }
   if (mask) {
     af_block_sum<2>(part, red);
-    if (threadIdx.x == 0) {
-      float* slot = af_sum_slot(sums);
-      atomicAdd(slot, part[0]);
-      atomicAdd(slot + 1, part[1]);
-    }
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
   }
 }
 
@@ -311,10 +307,10 @@ extern "C" int arflow_warp_nearest_bwd(const float* gout, const float* flow, flo
 }
 
 // called by arflow_census_fwd / arflow_census_bwd (photo.hip) for radius > 3
-int census_any_fwd(const float* im_a, const float* im_b, const float* mask, float* ham, float* dham, float* sums, int B,
-                   int H, int W, int R, hipStream_t st) {
+int census_any_fwd(const float* im_a, const float* im_b, const float* mask, float* ham, float* dham, float* sums, int nrows,
+                   int B, int H, int W, int R, hipStream_t st) {
   hipLaunchKernelGGL(census_any_fwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, st, im_a, im_b, mask, ham, dham, sums,
-                     H, W, R);
+                     nrows, H, W, R);
   return af_launch_status();
 }
 int census_any_bwd(const float* im_a, const float* im_b, const float* gham, const float* scale, float* g_im_b, int B, int H,

@@ -43,12 +43,15 @@ __global__ __launch_bounds__(TX* TY) void census_fwd_kernel(const float* __restr
                                                             const float* __restrict__ mask,
                                                             float* __restrict__ ham_out,
                                                             float* __restrict__ dham_out,
-                                                            float* __restrict__ sums, int nimg, int H, int W) {
+                                                            float* __restrict__ sums, int nrows, int nimg, int H, int W) {
   __shared__ float ga[TY + 2 * R][TX + 2 * R + 1];
   __shared__ float gb[TY + 2 * R][TX + 2 * R + 1];
   __shared__ float red[2 * (TX * TY / 64)];
   int btx_, bty_, b;
-  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) return;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) {
+    if (mask && threadIdx.x == 0) af_store_partial(sums, nrows, 0.f, 0.f, 0.f);  // padding workgroup: its row must be defined
+    return;
+  }
   const int ty0 = bty_ * TY, tx0 = btx_ * TX;
   const long ims = 3L * H * W;
   load_gray_tile<R>(ga, im_a + b * ims, H, W, ty0, tx0);
@@ -85,11 +88,7 @@ __global__ __launch_bounds__(TX* TY) void census_fwd_kernel(const float* __restr
   }
   if (mask) {
     af_block_sum<2>(part, red);
-    if (threadIdx.x == 0) {
-      float* slot = af_sum_slot(sums);
-      atomicAdd(slot, part[0]);
-      atomicAdd(slot + 1, part[1]);
-    }
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
   }
 }
 
@@ -163,13 +162,16 @@ namespace census4 {
 template <int R>
 __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ im_a, const float* __restrict__ im_b,
                                                  const float* __restrict__ mask, float* __restrict__ ham_out,
-                                                 float* __restrict__ dham_out, float* __restrict__ sums, int nimg,
+                                                 float* __restrict__ dham_out, float* __restrict__ sums, int nrows, int nimg,
                                                  int H, int W) {
   __shared__ __attribute__((aligned(16))) float ga[ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float gb[ROWS * PITCH];
   __shared__ float red[2 * (NT / 64)];
   int btx, bty, b;
-  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) return;
+  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) {
+    if (mask && threadIdx.x == 0) af_store_partial(sums, nrows, 0.f, 0.f, 0.f);  // padding workgroup: its row must be defined
+    return;
+  }
   const int ty0 = bty * TYH, tx0 = btx * TXW;
   const long ims = 3L * H * W;
   load_gray<R>(ga, im_a + b * ims, H, W, ty0, tx0);
@@ -225,11 +227,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ im_a,
   }
   if (mask) {
     af_block_sum<2>(part, red);
-    if (threadIdx.x == 0) {
-      float* slot = af_sum_slot(sums);
-      atomicAdd(slot, part[0]);
-      atomicAdd(slot + 1, part[1]);
-    }
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
   }
 }
 
@@ -309,8 +307,8 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ im_a,
 }  // namespace
 
 // radius > 3: the one-thread-per-pixel kernels of generic.hip (TernaryLoss(max_distance > 3), no shipped config)
-int census_any_fwd(const float* im_a, const float* im_b, const float* mask, float* ham, float* dham, float* sums, int B,
-                   int H, int W, int R, hipStream_t st);
+int census_any_fwd(const float* im_a, const float* im_b, const float* mask, float* ham, float* dham, float* sums, int nrows,
+                   int B, int H, int W, int R, hipStream_t st);
 int census_any_bwd(const float* im_a, const float* im_b, const float* gham, const float* scale, float* g_im_b, int B, int H,
                    int W, int R, hipStream_t st);
 
@@ -324,29 +322,26 @@ extern "C" int arflow_census_fwd(const float* im_a, const float* im_b, const flo
   AF_REQUIRE(radius >= 1 && radius <= 16, ARFLOW_EPARAM);
   if (mask) AF_REQUIRE_PTR(sums);
   hipStream_t st = (hipStream_t)stream;
-  if (mask) {
-    hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
-    if (e != hipSuccess) return af_hip_status(e);
-  }
+  const int nrows = af_sums_rows(B, H, W);
   if (radius > 3) {
     AF_REQUIRE(H <= 65535, ARFLOW_ESHAPE);
-    return census_any_fwd(im_a, im_b, mask, ham, dham, sums, B, H, W, radius, st);
+    return census_any_fwd(im_a, im_b, mask, ham, dham, sums, nrows, B, H, W, radius, st);
   }
   if ((W & 3) == 0) {
     namespace c4 = census4;
     dim3 g4(af_grid_for_tiles((long)af_cdiv(W, c4::TXW) * af_cdiv(H, c4::TYH) * B));
     switch (radius) {
-      case 1: hipLaunchKernelGGL(c4::fwd_kernel<1>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
-      case 2: hipLaunchKernelGGL(c4::fwd_kernel<2>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
-      default: hipLaunchKernelGGL(c4::fwd_kernel<3>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
+      case 1: hipLaunchKernelGGL(c4::fwd_kernel<1>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, nrows, B, H, W); break;
+      case 2: hipLaunchKernelGGL(c4::fwd_kernel<2>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, nrows, B, H, W); break;
+      default: hipLaunchKernelGGL(c4::fwd_kernel<3>, g4, dim3(c4::NT), 0, st, im_a, im_b, mask, ham, dham, sums, nrows, B, H, W); break;
     }
     return af_launch_status();
   }
   dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
   switch (radius) {
-    case 1: hipLaunchKernelGGL(census_fwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
-    case 2: hipLaunchKernelGGL(census_fwd_kernel<2>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
-    default: hipLaunchKernelGGL(census_fwd_kernel<3>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, B, H, W); break;
+    case 1: hipLaunchKernelGGL(census_fwd_kernel<1>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, nrows, B, H, W); break;
+    case 2: hipLaunchKernelGGL(census_fwd_kernel<2>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, nrows, B, H, W); break;
+    default: hipLaunchKernelGGL(census_fwd_kernel<3>, grid, dim3(TX * TY), 0, st, im_a, im_b, mask, ham, dham, sums, nrows, B, H, W); break;
   }
   return af_launch_status();
 }

@@ -79,7 +79,7 @@ __device__ __forceinline__ float diff_y(const SmoothArgs& a, const float* f, int
 // partial sums meet in the slotted rows (9216 workgroups x 2 atomics over 64 rows serialised ~290 deep at
 // 384 x 640).
 template <int CI>
-__global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __restrict__ sums, int rows) {
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __restrict__ sums, int nrows, int rows) {
   __shared__ float red[2 * 4];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
   const int o = a.order;
@@ -102,11 +102,7 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(SmoothArgs a, float* __
     }
   }
   af_block_sum<2>(part, red);
-  if (threadIdx.x == 0) {
-    float* slot = af_sum_slot(sums);
-    atomicAdd(slot, part[0]);
-    atomicAdd(slot + 1, part[1]);
-  }
+  if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
 }
 
 template <int CI>
@@ -199,16 +195,15 @@ extern "C" int arflow_smooth_fwd(const float* flow, const float* img, float* sum
   if (rc) return rc;
   AF_REQUIRE_PTR(sums);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
-  if (e != hipSuccess) return af_hip_status(e);
+  const int nrows = af_sums_rows(B, H, W);
   SmoothArgs a{flow, img, Ci, H, W, flow_bstride, flow_scale, alpha, order, wmode, penalty};
   long rows = (long)af_cdiv(W, 256) * H * B / 2048;
   rows = rows < 1 ? 1 : (rows > 8 ? 8 : rows);
   const dim3 grid(af_cdiv(W, 256), af_cdiv(H, rows), B);
   if (Ci == 3)
-    hipLaunchKernelGGL(smooth_fwd_kernel<3>, grid, dim3(256), 0, st, a, sums, (int)rows);
+    hipLaunchKernelGGL(smooth_fwd_kernel<3>, grid, dim3(256), 0, st, a, sums, nrows, (int)rows);
   else
-    hipLaunchKernelGGL(smooth_fwd_kernel<0>, grid, dim3(256), 0, st, a, sums, (int)rows);
+    hipLaunchKernelGGL(smooth_fwd_kernel<0>, grid, dim3(256), 0, st, a, sums, nrows, (int)rows);
   return af_launch_status();
 }
 

@@ -70,12 +70,15 @@ __global__ __launch_bounds__(TX* TY) void photo_fwd_kernel(const float* __restri
                                                            const float* __restrict__ rec,
                                                            const float* __restrict__ mask,
                                                            float* __restrict__ ssim_map,
-                                                           float* __restrict__ sums, int nimg, int C, int H, int W) {
+                                                           float* __restrict__ sums, int nrows, int nimg, int C, int H, int W) {
   __shared__ float tx[TY + 2][TX + 3];  // x = recons*mask
   __shared__ float ty[TY + 2][TX + 3];  // y = im*mask
   __shared__ float red[3 * (TX * TY / 64)];
   int btx_, bty_, b;
-  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) return;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx_, bty_, b)) {
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, 0.f, 0.f, 0.f);  // padding workgroup: its row must be defined
+    return;
+  }
   const int ty0 = bty_ * TY, tx0 = btx_ * TX;
   const long cs = (long)H * W;
   const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
@@ -112,12 +115,7 @@ __global__ __launch_bounds__(TX* TY) void photo_fwd_kernel(const float* __restri
     }
   }
   af_block_sum<3>(part, red);
-  if (threadIdx.x == 0) {
-    float* slot = af_sum_slot(sums);
-    atomicAdd(slot, part[0]);
-    atomicAdd(slot + 1, part[1]);
-    atomicAdd(slot + 2, part[2]);
-  }
+  if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], part[2]);
 }
 
 // d dist_w / d x_r = -(1/2) (alpha_w + beta_w x_r + gamma_w y_r) where 0 <= (1-S)/2 <= 1, else 0.
@@ -291,12 +289,15 @@ __device__ __forceinline__ float stage(float* __restrict__ X, float* __restrict_
 
 __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ im, const float* __restrict__ rec,
                                                  const float* __restrict__ mask, float* __restrict__ ssim_map,
-                                                 float* __restrict__ sums, int nimg, int C, int H, int W) {
+                                                 float* __restrict__ sums, int nrows, int nimg, int C, int H, int W) {
   __shared__ __attribute__((aligned(16))) float X[(TYH + 2) * P];
   __shared__ __attribute__((aligned(16))) float Y[(TYH + 2) * P];
   __shared__ float red[3 * (NT / 64)];
   int btx, bty, b;
-  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) return;
+  if (!af_tile_of_block((W + TXW - 1) / TXW, (H + TYH - 1) / TYH, nimg, btx, bty, b)) {
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, 0.f, 0.f, 0.f);  // padding workgroup: its row must be defined
+    return;
+  }
   const int ty0 = bty * TYH, tx0 = btx * TXW;
   const long cs = (long)H * W;
   const int xg = threadIdx.x & 15, ly = threadIdx.x >> 4;
@@ -337,12 +338,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ im, c
     }
   }
   af_block_sum<3>(part, red);
-  if (threadIdx.x == 0) {
-    float* slot = af_sum_slot(sums);
-    atomicAdd(slot, part[0]);
-    atomicAdd(slot + 1, part[1]);
-    atomicAdd(slot + 2, part[2]);
-  }
+  if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], part[2]);
 }
 
 __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ im, const float* __restrict__ rec,
@@ -455,16 +451,15 @@ extern "C" int arflow_photo_fwd(const float* im, const float* recons, const floa
   AF_REQUIRE_PTR(sums);
   AF_REQUIRE(B > 0 && C > 0 && H >= 3 && W >= 3 && B <= 65535, ARFLOW_ESHAPE);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, AF_SUMS_BYTES, st);
-  if (e != hipSuccess) return af_hip_status(e);
+  const int nrows = af_sums_rows(B, H, W);
   if ((W & 3) == 0) {
     namespace p4 = photo4;
     dim3 g4(af_grid_for_tiles((long)af_cdiv(W, p4::TXW) * af_cdiv(H, p4::TYH) * B));
-    hipLaunchKernelGGL(p4::fwd_kernel, g4, dim3(p4::NT), 0, st, im, recons, mask, ssim_map, sums, B, C, H, W);
+    hipLaunchKernelGGL(p4::fwd_kernel, g4, dim3(p4::NT), 0, st, im, recons, mask, ssim_map, sums, nrows, B, C, H, W);
     return af_launch_status();
   }
   dim3 grid(af_grid_for_tiles((long)af_cdiv(W, TX) * af_cdiv(H, TY) * B));
-  hipLaunchKernelGGL(photo_fwd_kernel, grid, dim3(TX * TY), 0, st, im, recons, mask, ssim_map, sums, B, C, H, W);
+  hipLaunchKernelGGL(photo_fwd_kernel, grid, dim3(TX * TY), 0, st, im, recons, mask, ssim_map, sums, nrows, B, C, H, W);
   return af_launch_status();
 }
 

@@ -74,16 +74,21 @@ def stop_kernel_timing():
     return out
 
 
-NSLOT, SLOT_STRIDE = 256, 32  # ARFLOW_NSLOT / ARFLOW_SLOT_STRIDE of include/arflow_hip.h
+SUM_COLS = 4  # ARFLOW_SUM_COLS of include/arflow_hip.h
 
 
-def _new_sums(device):
-    return torch.empty(NSLOT * SLOT_STRIDE, device=device, dtype=torch.float32)
+def _new_sums(device, B, H, W):
+    """Per-workgroup partial rows of a reduction kernel over a [B, *, H, W] problem (every row is written by the
+    call: no initialisation needed)."""
+    rows = _lib.load().arflow_sums_rows(int(B), int(H), int(W))
+    if rows <= 0:
+        _lib.check(rows, 'arflow_sums_rows')
+    return torch.empty(rows * SUM_COLS, device=device, dtype=torch.float32)
 
 
 def _fold_sums(buf, k):
-    """Slotted partial sums -> the k reduced quantities (one tiny reduction kernel)."""
-    return buf.view(NSLOT, SLOT_STRIDE)[:, :k].sum(0)
+    """Partial rows -> the k reduced quantities (one tiny reduction kernel, fixed order: reproducible)."""
+    return buf.view(-1, SUM_COLS)[:, :k].sum(0)
 
 
 def _call(name, *args, key=None):
@@ -587,7 +592,7 @@ class CensusLossFunction(torch.autograd.Function):
         if C != 3 or im_b.shape != im_a.shape or mask.shape != (B, 1, H, W):
             raise ValueError('census_loss expects [B,3,H,W] images and a [B,1,H,W] mask')
         r = int(patch_size) // 2
-        buf = _new_sums(im_a.device)
+        buf = _new_sums(im_a.device, B, H, W)
         dham = torch.empty(B, 1, H, W, device=im_a.device, dtype=torch.float32)
         with torch.cuda.device_of(im_a):
             _call('arflow_census_fwd', _p(im_a), _p(im_b), _p(mask), None, _p(dham), _p(buf), B, H, W, r, _stream(),
@@ -638,7 +643,7 @@ class CensusWarpLossFunction(torch.autograd.Function):
             if occ_small.shape != (B, 1, H // 4, W // 4):
                 raise ValueError('occ_small must be the [B,1,H/4,W/4] range map')
         r = int(patch_size) // 2
-        buf = _new_sums(gray_a.device)
+        buf = _new_sums(gray_a.device, B, H, W)
         dham = torch.empty(B, 1, H, W, device=gray_a.device, dtype=torch.float32)
         mask = torch.empty(B, 1, H, W, device=gray_a.device, dtype=torch.float32)
         with torch.cuda.device_of(gray_a):
@@ -732,7 +737,7 @@ class PhotoSumsFunction(torch.autograd.Function):
         im, recons = im.contiguous(), recons.contiguous()
         mask = None if mask is None else mask.contiguous()
         B, C, H, W = im.shape
-        buf = _new_sums(im.device)
+        buf = _new_sums(im.device, B, H, W)
         with torch.cuda.device_of(im):
             _call('arflow_photo_fwd', _p(im), _p(recons), _p(mask), None, _p(buf), B, C, H, W, _stream(),
                   key=(B, C, H, W))
@@ -792,7 +797,7 @@ class SSIMFunction(torch.autograd.Function):
         x, y = x.contiguous(), y.contiguous()
         B, C, H, W = x.shape
         out = torch.empty(B, C, H - 2, W - 2, device=x.device, dtype=torch.float32)
-        sums = _new_sums(x.device)
+        sums = _new_sums(x.device, B, H, W)
         with torch.cuda.device_of(x):
             # kernel convention: SSIM(recons*mask, im*mask) -> x plays "recons", y plays "im"
             _call('arflow_photo_fwd', _p(y), _p(x), None, _p(out), _p(sums), B, C, H, W, _stream())
@@ -830,7 +835,7 @@ class SmoothSumsFunction(torch.autograd.Function):
         Ci = img.shape[1]
         if img.shape[0] != B or img.shape[2:] != flow.shape[2:]:
             raise ValueError('smoothness: image and flow must share batch and spatial size')
-        buf = _new_sums(flow.device)
+        buf = _new_sums(flow.device, B, H, W)
         args = (B, Ci, H, W, fbs, float(flow_scale), float(alpha), int(order), int(wmode), int(penalty))
         with torch.cuda.device_of(flow):
             _call('arflow_smooth_fwd', _p(flow), _p(img), _p(buf), *args, _stream(), key=(B, Ci, H, W))

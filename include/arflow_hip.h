@@ -52,12 +52,13 @@ typedef void* arflow_stream_t; /* hipStream_t */
 #define ARFLOW_COORDS_ABS 2     /* OR into `variant` / `mode` of splat_map / coord_mask: input holds
                                    absolute coordinates instead of a flow */
 
-/* Reduction outputs ("sums") are NOT single scalars: to avoid thousands of same-address atomics every
- * workgroup adds its partial into one of ARFLOW_NSLOT rows, each on its own 128-byte line.
- * A `sums` argument points to ARFLOW_NSLOT*ARFLOW_SLOT_STRIDE floats (zero-filled by the callee);
- * quantity k is  sum_{s<NSLOT} sums[s*ARFLOW_SLOT_STRIDE + k]. */
-#define ARFLOW_NSLOT 256
-#define ARFLOW_SLOT_STRIDE 32
+/* Reduction outputs ("sums") are NOT single scalars: every workgroup of a reduction kernel STORES its partial sums into
+ * its own row of ARFLOW_SUM_COLS floats and zero-fills the rows beyond the kernel's grid -- no zero-fill launch, no
+ * atomics, and a value that does not depend on the order the workgroups finish in.  A `sums` argument points to
+ * arflow_sums_rows(B, H, W) * ARFLOW_SUM_COLS floats (need not be initialised; every row is written by the call);
+ * quantity k is  sum over all rows r of  sums[r * ARFLOW_SUM_COLS + k]. */
+#define ARFLOW_SUM_COLS 4
+int arflow_sums_rows(int B, int H, int W);
 
 int arflow_abi_version(void);
 const char* arflow_strerror(int code);

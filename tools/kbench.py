@@ -101,7 +101,7 @@ def main():
     fl2 = 1.0 * torch.randn(B, 2, H0 // 4, W0 // 4, device=dev, generator=g)
     rec3 = torch.empty_like(im1)
     dham = torch.empty(B, 1, H0, W0, device=dev)
-    sums = torch.empty(256 * 32, device=dev)
+    sums = torch.empty(4 * lib.arflow_sums_rows(B, H0, W0), device=dev)  # rows of the largest problem timed below
     gfl0 = torch.empty_like(fl0)
     sm = torch.empty(B, 3, H0 // 4, W0 // 4, device=dev)
     coef = torch.ones(2, device=dev)
