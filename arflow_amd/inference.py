@@ -3,7 +3,7 @@
 (README.md:32-50:  inference.py -m <ckpt> -s 384 640 -i img1 img2 [img0 img1 img2]); the fork's own
 inference.py only drives its probabilistic models.
 
-    python -m arflow_amd.inference -s 384 640 -i a.png b.png [-m ckpt.pth.tar] [-o flow.flo] [--model pwclite]
+    python -m arflow_amd.inference -s 384 640 -i a.png b.png [-m ckpt.pth.tar] [-o flow.flo] [--arch pwclite|pwclite_uflow|uflow]
 
 Runs on the GPU through the HIP kernels.  Without -m the network is seeded-random (no checkpoint ships
 with the reference: .MISSING_LARGE_BLOBS), which still exercises the whole path.
