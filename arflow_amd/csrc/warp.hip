@@ -41,30 +41,51 @@ constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24;
 // thread are issued before the first LDS write and none is branched around (a slot outside the window
 // reads the plane's first 16 bytes instead): with `if (inside) win[..] = load` per slot hipcc waits for
 // every load before issuing the next -- 2 x CCH serialised round trips per chunk.
-template <int WQ, int CCH, typename TS>
-__device__ __forceinline__ void stage_window(float* __restrict__ win, const TS* __restrict__ sp, int c0, int C,
-                                             int ss, int Ws, int ax0, int by0, int bh) {
-  constexpr int WP = 4 * WQ, ITER = (HMAX * WQ + NT - 1) / NT;
-  const int per = bh * WQ;
-  float4 v[CCH][ITER];
+// The window of a chunk travels in two halves so that the NEXT chunk's global loads are in flight while the current
+// chunk is computed (round 2: the kernels are latency chains -- 16 chunks x (load -> barrier -> 4 LDS taps -> barrier)
+// per workgroup; with the loads issued one chunk ahead the chain is one round trip shorter per chunk):
+//   window_load  : all loads of a thread, none branched around (a slot outside the window reads the plane's first
+//                  16 bytes instead: with `if (inside) load` hipcc waits for every load before issuing the next);
+//   window_store : registers -> LDS.
+template <int WQ>
+struct WindowPlan {
+  static constexpr int ITER = (HMAX * WQ + NT - 1) / NT;
   bool ok[ITER];
   int dst[ITER];
+  long off[ITER];
+};
+template <int WQ>
+__device__ __forceinline__ WindowPlan<WQ> window_plan(int Ws, int ax0, int by0, int bh) {
+  constexpr int WP = 4 * WQ;
+  WindowPlan<WQ> pl;
+  const int per = bh * WQ;
 #pragma unroll
-  for (int it = 0; it < ITER; ++it) {
+  for (int it = 0; it < WindowPlan<WQ>::ITER; ++it) {
     const int i = threadIdx.x + it * NT;
     const int r = i / WQ, xs = i - r * WQ;
-    ok[it] = i < per && ax0 + 4 * xs < Ws;
-    dst[it] = r * WP + 4 * xs;
-    const long off = ok[it] ? (long)(by0 + r) * Ws + ax0 + 4 * xs : 0;
-#pragma unroll
-    for (int c = 0; c < CCH; ++c)
-      v[c][it] = load4(sp + (long)min(c0 + c, C - 1) * ss + off);
+    pl.ok[it] = i < per && ax0 + 4 * xs < Ws;
+    pl.dst[it] = r * WP + 4 * xs;
+    pl.off[it] = pl.ok[it] ? (long)(by0 + r) * Ws + ax0 + 4 * xs : 0;
   }
+  return pl;
+}
+template <int WQ, int CCH, typename TS>
+__device__ __forceinline__ void window_load(float4 (&v)[CCH][WindowPlan<WQ>::ITER], const WindowPlan<WQ>& pl,
+                                            const TS* __restrict__ sp, int c0, int C, int ss) {
 #pragma unroll
-  for (int it = 0; it < ITER; ++it)
+  for (int it = 0; it < WindowPlan<WQ>::ITER; ++it)
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) v[c][it] = load4(sp + (long)min(max(c0 + c, 0), C - 1) * ss + pl.off[it]);
+}
+template <int WQ, int CCH>
+__device__ __forceinline__ void window_store(float* __restrict__ win, const float4 (&v)[CCH][WindowPlan<WQ>::ITER],
+                                             const WindowPlan<WQ>& pl, int c0, int C) {
+  constexpr int WP = 4 * WQ;
+#pragma unroll
+  for (int it = 0; it < WindowPlan<WQ>::ITER; ++it)
 #pragma unroll
     for (int c = 0; c < CCH; ++c)
-      if (ok[it] && c0 + c < C) *reinterpret_cast<float4*>(win + c * HMAX * WP + dst[it]) = v[c][it];
+      if (pl.ok[it] && c0 + c < C) *reinterpret_cast<float4*>(win + c * HMAX * WP + pl.dst[it]) = v[c][it];
 }
 
 template <int WQ, int CCH, typename TS>  // window row = WQ float4
@@ -72,9 +93,14 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
                                     const TapPlan& p, bool inside, int C, int ss, int os, int Ws, int ax0, int by0,
                                     int bh, int l0, int l1, int l2, int l3) {
   constexpr int WP = 4 * WQ;
-  // channels are independent: at small levels they are spread over gridDim.y workgroups per tile
-  for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
-    stage_window<WQ, CCH, TS>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
+  const WindowPlan<WQ> pl = window_plan<WQ>(Ws, ax0, by0, bh);
+  float4 v[CCH][WindowPlan<WQ>::ITER];
+  const int step = gridDim.y * CCH;  // channels are independent: at small levels they are spread over gridDim.y workgroups
+  int c0 = blockIdx.y * CCH;
+  if (c0 < C) window_load<WQ, CCH, TS>(v, pl, sp, c0, C, ss);
+  for (; c0 < C; c0 += step) {
+    window_store<WQ, CCH>(win, v, pl, c0, C);
+    if (c0 + step < C) window_load<WQ, CCH, TS>(v, pl, sp, c0 + step, C, ss);  // next chunk: in flight during this one
     __syncthreads();
     if (inside) {
 #pragma unroll
@@ -241,11 +267,29 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
                                     int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
                                     float& gix, float& giy) {
   constexpr int WP = 4 * WQ;
-  for (int c0 = blockIdx.y * CCH; c0 < C; c0 += gridDim.y * CCH) {
+  using fwd_win::WindowPlan;
+  const WindowPlan<WQ> pl = fwd_win::window_plan<WQ>(Ws, ax0, by0, bh);
+  float4 v[CCH][WindowPlan<WQ>::ITER];
+  float gn[CCH];  // the next chunk's output gradients travel with its window
+  auto fetch_g = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) gn[c] = (inside && c0 + c < C) ? gop[(long)(c0 + c) * os] : 0.f;
+  };
+  const int step = gridDim.y * CCH;
+  int c0 = blockIdx.y * CCH;
+  if (c0 < C) {
+    fetch_g(c0);
+    fwd_win::window_load<WQ, CCH, TS>(v, pl, sp, c0, C, ss);
+  }
+  for (; c0 < C; c0 += step) {
     float g[CCH];
 #pragma unroll
-    for (int c = 0; c < CCH; ++c) g[c] = (inside && c0 + c < C) ? gop[(long)(c0 + c) * os] : 0.f;
-    fwd_win::stage_window<WQ, CCH, TS>(win, sp, c0, C, ss, Ws, ax0, by0, bh);
+    for (int c = 0; c < CCH; ++c) g[c] = gn[c];
+    fwd_win::window_store<WQ, CCH>(win, v, pl, c0, C);
+    if (c0 + step < C) {
+      fetch_g(c0 + step);
+      fwd_win::window_load<WQ, CCH, TS>(v, pl, sp, c0 + step, C, ss);
+    }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < CCH; ++c) {
