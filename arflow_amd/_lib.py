@@ -39,6 +39,11 @@ PROTOTYPES = {
     'arflow_corr_general_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     'arflow_featnorm_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
     'arflow_featnorm_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
+    'arflow_level_acc_rows': [c_i, c_i, c_i, c_i, c_i],
+    'arflow_level_moments': [c_fp, c_fp, c_fp, c_i, c_l, c_fp],
+    'arflow_level_warp_fwd': [c_fp, c_fp, c_fp, c_l, c_i, c_i, c_fp, c_fp, c_l, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_level_corr_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
+    'arflow_level_corr_bwd': [c_fp, c_l, c_fp, c_fp, c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_bias_act_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_l, c_f, c_fp],
     'arflow_bias_act_bwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_l, c_f, c_fp],
     'arflow_warp_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],

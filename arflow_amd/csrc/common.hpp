@@ -41,6 +41,22 @@ static inline int af_hip_status(hipError_t e) {
 }
 static inline int af_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Launch-shape helpers shared by translation units (the level entry points size one accumulator for either producer).
+// Few tiles (coarse pyramid levels): the 4-channel chunks of a tile are spread over up to C/4 workgroups (gridDim.y)
+// until ~2048 workgroups are in flight, instead of one workgroup walking all channels serially.
+static inline unsigned af_channel_split(long tiles, int C) {
+  unsigned n = 1;
+  while ((long)n * 2 <= C / 4 && tiles * n * 2 <= 2048) n *= 2;
+  return n;
+}
+// featnorm reduction passes: enough workgroups to fill the chip (~2048) without slicing a sample finer than one trip per block
+static inline unsigned af_blocks_per_sample(int B, long n, int floats_per_block) {
+  long nb = (n + floats_per_block - 1) / floats_per_block;
+  const long want = (2048 + B - 1) / B;
+  if (nb > want) nb = want;
+  return (unsigned)(nb < 1 ? 1 : nb);
+}
+
 // Sum over the 64 lanes of a wave; every lane gets the total.
 __device__ __forceinline__ float af_wave_sum(float v) {
 #pragma unroll

@@ -400,6 +400,50 @@ static int corr_fwd_impl(const float* x1, const float* x2, float* out, long out_
   }
 }
 
+// Level forward, second launch: cost volume of the NORMALISED pair straight from the raw maps
+// (corr_v2::fwd_kernel<.., NORM = true>): volume (+ fused LeakyReLU and sign words) into `out`, the normalised first
+// map into `x1n` (both with a batch stride: slots of the decoder's concatenated input), the statistics into `stats`.
+extern "C" int arflow_level_corr_fwd(const float* x1, const float* x2w, const double* acc, int acc_rows, int norm_mode,
+                                     float* out, long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits,
+                                     float* stats, int B, int C, int H, int W, int max_disp, float negative_slope,
+                                     arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2w);
+  AF_REQUIRE_PTR(acc);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE_PTR(stats);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535 && acc_rows >= 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(corr_v2::eligible(C, W, max_disp), ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode == ARFLOW_FEATNORM_JOINT || norm_mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
+  const long vol = (long)corr_v2::N * corr_v2::N * H * W;
+  AF_REQUIRE(out_bstride >= vol && out_bstride % 4 == 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(x1n == nullptr || (x1n_bstride >= (long)C * H * W && x1n_bstride % 4 == 0), ARFLOW_ESHAPE);
+  const corr_v2::NormArgs na{acc, acc_rows, norm_mode, x1n, x1n_bstride, stats};
+  return corr_v2::launch_fwd(x1, x2w, out, sign_bits, B, C, H, W, negative_slope, (hipStream_t)stream, out_bstride, &na);
+}
+
+// Level backward, first launch: gradients w.r.t. the NORMALISED maps from the raw second map and the saved normalised
+// first map (corr_v2::bwd_kernel<.., NORM = true>).  gx1n / gx2n: [B,C,H,W] contiguous.
+extern "C" int arflow_level_corr_bwd(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
+                                     long x1n_bstride, const float* x2w, const float* stats, float* gx1n, float* gx2n,
+                                     int B, int C, int H, int W, int max_disp, float negative_slope,
+                                     arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gout);
+  AF_REQUIRE_PTR(x1n);
+  AF_REQUIRE_PTR(x2w);
+  AF_REQUIRE_PTR(stats);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(corr_v2::eligible(C, W, max_disp), ARFLOW_EPARAM);
+  AF_REQUIRE(negative_slope == 1.0f || sign_bits != nullptr, ARFLOW_ENULL);
+  const long vol = (long)corr_v2::N * corr_v2::N * H * W;
+  AF_REQUIRE(gout_bstride >= vol && gout_bstride % 4 == 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(x1n_bstride >= (long)C * H * W && x1n_bstride % 4 == 0, ARFLOW_ESHAPE);
+  return corr_v2::launch_bwd(gout, nullptr, negative_slope == 1.0f ? nullptr : sign_bits, negative_slope, x1n, x2w, gx1n,
+                             gx2n, B, C, H, W, (hipStream_t)stream, gout_bstride, 0, x1n_bstride, stats);
+}
+
 static int corr_bwd_impl(const float* gout, long gout_bstride, const float* out, long out_bstride,
                          const unsigned* sign_bits, const float* x1, const float* x2, float* gx1, float* gx2, int B, int C,
                          int H, int W, int max_disp, float negative_slope, arflow_stream_t stream);

@@ -19,6 +19,7 @@
 //   * workgroup -> tile order is XCD-aware (tiles sharing halos share an L2).
 #pragma once
 #include "common.hpp"
+#include "featnorm_stats.hpp"
 
 namespace corr_v2 {
 
@@ -110,13 +111,30 @@ inline unsigned grid_for_tiles(int T) { return 8u * (unsigned)((T + 7) / 8); }
 // chunks g, g+G, ... through its own DMA ring, and the groups' accumulators meet through LDS at the end
 // (float atomics into the volume were 6x slower than no split at all).  Needs (C / 4) % G == 0; one such
 // workgroup (G = 4: 12 waves, 124 KB of LDS) fills a CU.
-template <int NBUF, int G>
+// NORM (level kernels): the feature normalisation in front of the cost volume
+// (normalize_features, models/pwclite_uflow.py:30-38 / models/uflow_model.py:8-50) folded into this launch.  x1 and x2
+// are the RAW first map and the raw (warped) second map; the per-sample (mu, sigma) come from the partial-moment rows
+// the warp launch (or the moment pass) left in `acc`.  With x1n = (x1 - mu) / sigma formed in registers,
+//     corr(x1n, (x2 - mu) / sigma)[p, d] = (sum_c x1n[c,p] x2[c,p+d]  -  mu * sum_c x1n[c,p]) / (C sigma)
+// for displacements inside the image and 0 outside (models/correlation_native.py:13-23 zero-pads the NORMALISED map),
+// so the second normalised map is never formed and the first one is written once (the decoder concatenates it,
+// models/pwclite_uflow.py:218-222) from the registers that feed the FMAs: no moment pass, no apply pass.
+struct NormArgs {
+  const double* acc;  // [B][nrows][4] partial (sum x1, sum x1^2, sum x2, sum x2^2)
+  int nrows, mode;    // ARFLOW_FEATNORM_JOINT / _AVG
+  float* x1n;         // normalised first map out (batch stride x1n_bs floats), may be null
+  long x1n_bs;
+  float* stats;       // [B][4] (m1, m2, mu, sigma) for the backward
+};
+
+template <int NBUF, int G, bool NORM = false>
 // (the 4-buffer ring of the few-tiles form needs 2 waves/SIMD worth of registers: asking for 3 only earned a
 // "failed to meet occupancy target" remark)
 __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
                                                         float* __restrict__ out, unsigned* __restrict__ sign_bits,
                                                         int nimg, int C, int H, int W, float inv_c, float slope,
-                                                        long obs /* floats between the volumes of two samples */) {
+                                                        long obs /* floats between the volumes of two samples */,
+                                                        NormArgs na) {
   constexpr int BUF = SRC_FLOATS + X1_FLOATS, RING = NBUF * BUF;
   static_assert(G == 1 || G * RING >= NW * N * 64 * PX, "the accumulator exchange reuses the rings");
   __shared__ __attribute__((aligned(16))) float lds_all[G * RING + TH * SP];  // + pad: prefetch runs a channel ahead
@@ -164,6 +182,26 @@ __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_ker
 #pragma unroll
       for (int p = 0; p < PX; ++p) acc[k][j][p] = 0.f;
 
+  // NORM: the sample's statistics while the first chunks are in flight (every wave adds the rows itself: no LDS)
+  float mu = 0.f, rs = 1.f;
+  float s1n[PX] = {0.f, 0.f, 0.f, 0.f};  // sum over channels of the normalised first map at the lane's 4 pixels
+  const int gy = ty0 + y, gx = tx0 + 4 * xg;
+  const bool lane_in = gy < H && gx < W;
+  float* x1n_p = nullptr;
+  if constexpr (NORM) {
+    featnorm::Moments m;
+    m.m1 = m.m2 = m.mu = 0.f, m.var = 1.f;
+    if (na.nrows > 0) m = featnorm::moments_of(na.acc + 4L * na.nrows * b, na.nrows, (long)C * cs, na.mode);
+    const float sd = sqrtf(m.var + 1e-16f);
+    mu = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m.mu)));
+    rs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / sd)));
+    if (na.stats && btx == 0 && bty == 0 && threadIdx.x == 0) {
+      float* st = na.stats + 4 * b;
+      st[0] = m.m1, st[1] = m.m2, st[2] = m.mu, st[3] = sd;
+    }
+    if (na.x1n) x1n_p = na.x1n + (long)b * na.x1n_bs + (long)gy * W + gx;
+  }
+
   for (int ch = 0; ch < nchunk; ++ch) {
     // chunk ch must have landed; the NBUF-2 younger chunks may stay in flight
     if (ch + NBUF - 2 < nchunk)
@@ -187,6 +225,16 @@ __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_ker
     for (int c = 0; c < CC; ++c) {
       const float* sc = s2 + c * SR * SP;
       f32x4 ta;
+      if constexpr (NORM) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          a[p] = (a[p] - mu) * rs;
+          s1n[p] += a[p];
+        }
+        // channel c of a chunk is written by wave c % 3 (wave id and c are scalar: a uniform branch)
+        if (x1n_p && lane_in && (c == wave || c == wave + NW))
+          *reinterpret_cast<float4*>(x1n_p + (long)((grp + ch * G) * CC + c) * cs) = make_float4(a[0], a[1], a[2], a[3]);
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         issue_window(k < 2 ? sc + (k + 1) * SP : sc + SR * SP, wn);
@@ -233,10 +281,26 @@ __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_ker
         }
       }
     }
+    if constexpr (NORM) {  // the groups' partial channel sums of the normalised first map meet the same way
+      __syncthreads();
+      f32x4* xs = reinterpret_cast<f32x4*>(lds_all) + wave * 64 + lane;
+      if (grp != 0) {
+        f32x4 t;
+        t.x = s1n[0], t.y = s1n[1], t.z = s1n[2], t.w = s1n[3];
+        xs[(grp - 1) * NW * 64] = t;
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll 1
+        for (int g = 1; g < G; ++g) {
+          const f32x4 t = xs[(g - 1) * NW * 64];
+          s1n[0] += t.x, s1n[1] += t.y, s1n[2] += t.z, s1n[3] += t.w;
+        }
+      }
+    }
     if (grp != 0) return;
   }
-  const int gy = ty0 + y, gx = tx0 + 4 * xg;
-  if (gy >= H || gx >= W) return;
+  if (!lane_in) return;
   float* ob = out + (long)b * obs + ((long)(3 * wave * N) * H + gy) * W + gx;
   unsigned sg[PX] = {0u, 0u, 0u, 0u};  // bit k*9+j: this wave's channel (3*wave+k)*9+j is positive
 #pragma unroll
@@ -246,7 +310,13 @@ __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_ker
       float v[PX];
 #pragma unroll
       for (int p = 0; p < PX; ++p) {
-        v[p] = acc[k][j][p] * inv_c;
+        if constexpr (NORM) {
+          const int yy = gy + 3 * wave + k - D, xx = gx + p + j - D;
+          const bool inb = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          v[p] = (acc[k][j][p] - (inb ? mu * s1n[p] : 0.f)) * (inv_c * rs);
+        } else {
+          v[p] = acc[k][j][p] * inv_c;
+        }
         sg[p] |= v[p] > 0.f ? 1u << (k * N + j) : 0u;
         v[p] = v[p] > 0.f ? v[p] : v[p] * slope;  // fused LeakyReLU (slope 1 = identity)
       }
@@ -261,14 +331,21 @@ __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_ker
 // mode 1: gx2[c,q] = (1/C) sum_{i,j} g[80-(i*9+j)][q+(i-4,j-4)] * x1[c][q+(i-4,j-4)]
 // ACT: how the fused LeakyReLU derivative is selected -- 0 none (slope 1), 1 sign of the forward output
 // `fout`, 2 the forward's compact sign words.
-template <int NBUF, int ACT>
+// NORM (level kernels): the backward of fwd_kernel<.., NORM = true>.  `x1` holds the NORMALISED first map x1n (batch
+// stride x1bs: the decoder's concatenated input keeps it), `x2` the RAW (warped) second map; (mu, sigma) come from
+// `stats`.  With x2n = (x2 - mu) / sigma inside the image and 0 outside,
+//   mode 0: d/d x1n[c,p] = (1 / (C sigma)) (sum_d g[d,p] x2[c,p+d]  -  mu * sum_{d: p+d inside} g[d,p])
+//   mode 1: d/d x2n[c,q] = (1 / C) sum_d g[d,q-d] x1n[c,q-d]
+// -- the gradients w.r.t. the NORMALISED maps; the normalisation's own backward follows in the warp launch.
+template <int NBUF, int ACT, bool NORM = false>
 __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ gout, const float* __restrict__ fout,
                                                     const unsigned* __restrict__ sign_bits, float slope,
                                                     const float* __restrict__ x1,
                                                     const float* __restrict__ x2, float* __restrict__ gx1,
                                                     float* __restrict__ gx2, int B, int C, int H, int W,
                                                     float inv_c, int mode_base, int nmodes,
-                                                    long gbs /* batch stride of gout */, long fbs /* of fout */) {
+                                                    long gbs /* batch stride of gout */, long fbs /* of fout */,
+                                                    long x1bs /* batch stride of x1 */, const float* __restrict__ stats) {
   constexpr int BUF = SRC_FLOATS;
   // Cross-wave sum of the per-wave partials.  Channel c of a chunk is OWNED by wave c % 3: the other two waves
   // publish their 4-pixel partials for it in LDS, the owner keeps its own in registers and, one iteration later
@@ -298,7 +375,7 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   }
   const int tx0 = btx * TW, ty0 = bty * TH;
   const long cs = (long)H * W;
-  const float* srcb = (mode == 0 ? x2 : x1) + (long)b * C * cs;
+  const float* srcb = mode == 0 ? x2 + (long)b * C * cs : x1 + (long)b * x1bs;
   float* dstb = (mode == 0 ? gx1 : gx2) + (long)b * C * cs;
   const float* gb = gout + (long)b * gbs;
   const float* fb = ACT == 1 ? fout + (long)b * fbs : nullptr;  // forward output: LeakyReLU derivative
@@ -423,6 +500,27 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   }
   // the g loads above are younger than the prologue DMA: drain everything once, then count exactly
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float nmg[PX] = {0.f, 0.f, 0.f, 0.f};  // NORM, mode 0: -mu * (this wave's share of the in-image gradient sum)
+  if constexpr (NORM) {
+    const float mu = stats[4 * b + 2], rs = 1.0f / stats[4 * b + 3];
+    if (mode == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int yy = gy + 3 * wave + k - D;
+        const bool rowin = yy >= 0 && yy < H;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+          for (int p = 0; p < PX; ++p) {
+            const int xx = gx + p + j - D;
+            nmg[p] += (rowin && xx >= 0 && xx < W) ? g[k][j][p] : 0.f;
+          }
+      }
+#pragma unroll
+      for (int p = 0; p < PX; ++p) nmg[p] *= -mu;
+      inv_c *= rs;
+    }
+  }
 
   float own[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // this wave's partials of the channels it owns
   const bool lane_in = gy < H && gx < W;
@@ -468,7 +566,7 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 #pragma unroll
     for (int c = 0; c < CC; ++c) {
       const float* sc = s2 + c * SR * SP;
-      float pa[PX] = {0.f, 0.f, 0.f, 0.f};
+      float pa[PX] = {nmg[0], nmg[1], nmg[2], nmg[3]};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         issue_window(k < 2 ? sc + (k + 1) * SP : sc + SR * SP, wn);  // next step (in-bounds past the end)
@@ -498,28 +596,35 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 4) == 0 && (C % CC) == 0; }
 
 inline int launch_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C, int H, int W,
-                      float slope, hipStream_t st, long obs = 0) {
+                      float slope, hipStream_t st, long obs = 0, const NormArgs* norm = nullptr) {
   if (obs == 0) obs = (long)N * N * H * W;
+  const NormArgs na = norm ? *norm : NormArgs{nullptr, 0, 0, nullptr, 0, nullptr};
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B;
   dim3 grid(grid_for_tiles(tiles));
   // many tiles: 4 workgroups per CU hide each other's DMA latency, keep LDS small (2 buffers);
   // few tiles: one workgroup per CU -> deeper ring so its own DMA runs 3 chunks ahead
   const float inv_c = 1.0f / (float)C;
-  if (tiles <= 160 && (C / CC) % 4 == 0 && C / CC >= 8)  // few tiles, >= 2 chunks per group: 4 channel groups per workgroup
-    hipLaunchKernelGGL((fwd_kernel<2, 4>), grid, dim3(NT * 4), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope, obs);
+#define CORR_V2_FWD(NB, GG, NN, THREADS) \
+  hipLaunchKernelGGL((fwd_kernel<NB, GG, NN>), grid, dim3(THREADS), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope, obs, na)
+  if (tiles <= 160 && (C / CC) % 4 == 0 && C / CC >= 8) {  // few tiles, >= 2 chunks per group: 4 channel groups per workgroup
+    if (norm) CORR_V2_FWD(2, 4, true, NT * 4); else CORR_V2_FWD(2, 4, false, NT * 4);
   // (2 groups at ~1 tile per CU, e.g. 48x80: 23.4 -> 26.1 us -- splitting only pays while CUs are idle)
-  else if (tiles >= 768)
-    hipLaunchKernelGGL((fwd_kernel<2, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope, obs);
-  else
-    hipLaunchKernelGGL((fwd_kernel<4, 1>), grid, dim3(NT), 0, st, x1, x2, out, sign_bits, B, C, H, W, inv_c, slope, obs);
+  } else if (tiles >= 768) {
+    if (norm) CORR_V2_FWD(2, 1, true, NT); else CORR_V2_FWD(2, 1, false, NT);
+  } else {
+    if (norm) CORR_V2_FWD(4, 1, true, NT); else CORR_V2_FWD(4, 1, false, NT);
+  }
+#undef CORR_V2_FWD
   return af_launch_status();
 }
 
 inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign_bits, float slope, const float* x1,
                       const float* x2,
-                      float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st, long gbs = 0, long fbs = 0) {
+                      float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st, long gbs = 0, long fbs = 0,
+                      long x1bs = 0, const float* stats = nullptr) {
   if (gbs == 0) gbs = (long)N * N * H * W;
   if (fbs == 0) fbs = (long)N * N * H * W;
+  if (x1bs == 0) x1bs = (long)C * H * W;
   const int nmodes = (gx1 ? 1 : 0) + (gx2 ? 1 : 0);
   if (nmodes == 0) return ARFLOW_OK;
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B * nmodes;
@@ -529,13 +634,20 @@ inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign
   const int act = sign_bits ? 2 : (fout ? 1 : 0);
   const float inv_c = 1.0f / (float)C;
   const int mb = gx1 ? 0 : 1;
-#define CORR_V2_BWD(NB, ACT)                                                                                      \
-  hipLaunchKernelGGL((bwd_kernel<NB, ACT>), grid, dim3(NT), 0, st, gout, fout, sign_bits, slope, x1, x2, gx1, gx2, \
-                     B, C, H, W, inv_c, mb, nmodes, gbs, fbs)
-  if (tiles >= 768) {
-    if (act == 2) CORR_V2_BWD(2, 2); else if (act == 1) CORR_V2_BWD(2, 1); else CORR_V2_BWD(2, 0);
+#define CORR_V2_BWD(NB, ACT, NN)                                                                                      \
+  hipLaunchKernelGGL((bwd_kernel<NB, ACT, NN>), grid, dim3(NT), 0, st, gout, fout, sign_bits, slope, x1, x2, gx1, gx2, \
+                     B, C, H, W, inv_c, mb, nmodes, gbs, fbs, x1bs, stats)
+  if (stats) {  // level kernels: always with the sign words of the fused LeakyReLU (ACT 2) or without activation (0)
+    if (act == 1) return ARFLOW_EPARAM;
+    if (tiles >= 768) {
+      if (act == 2) CORR_V2_BWD(2, 2, true); else CORR_V2_BWD(2, 0, true);
+    } else {
+      if (act == 2) CORR_V2_BWD(3, 2, true); else CORR_V2_BWD(3, 0, true);
+    }
+  } else if (tiles >= 768) {
+    if (act == 2) CORR_V2_BWD(2, 2, false); else if (act == 1) CORR_V2_BWD(2, 1, false); else CORR_V2_BWD(2, 0, false);
   } else {
-    if (act == 2) CORR_V2_BWD(3, 2); else if (act == 1) CORR_V2_BWD(3, 1); else CORR_V2_BWD(3, 0);  // ring of 3: 46 KB of LDS, 3 workgroups per CU (4: 56 KB, 2)
+    if (act == 2) CORR_V2_BWD(3, 2, false); else if (act == 1) CORR_V2_BWD(3, 1, false); else CORR_V2_BWD(3, 0, false);  // ring of 3: 46 KB of LDS, 3 workgroups per CU (4: 56 KB, 2)
   }
 #undef CORR_V2_BWD
   return af_launch_status();

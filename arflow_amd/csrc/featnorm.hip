@@ -13,6 +13,7 @@
 // for any mean / spread ratio) + one apply pass; backward = one pass for the two sums the chain rule
 // needs + one apply pass.  HBM-bound: 3 reads + 1 write of each tensor forward, 4 reads + 1 write backward.
 #include "common.hpp"
+#include "featnorm_stats.hpp"
 
 namespace {
 
@@ -22,73 +23,13 @@ constexpr int NT = 256, VPT = 16;  // floats per thread per tensor and trip (4 f
 // No zero-fill and no atomics (round 1 added into 8 slotted rows per sample after a hipMemsetAsync -- a separate
 // ~4 us GPU operation per call; ~120 workgroups adding into ONE address per sample had serialised at the L2).
 
-// sum over the block of NV doubles per thread; result in thread 0
+using featnorm::Moments;
+using featnorm::moments_from_totals;
+using featnorm::moments_of;
+using featnorm::sum_rows;
 template <int NV, int NTH = NT>
 __device__ __forceinline__ void block_sum_f64(double (&v)[NV], double* scratch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) scratch[k * (NTH / 64) + wave] = v[k];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      double s = 0.0;
-      for (int w = 0; w < NTH / 64; ++w) s += scratch[k * (NTH / 64) + w];
-      v[k] = s;
-    }
-  }
-}
-
-struct Moments {
-  float m1, m2, mu, rstd, var;
-};
-
-// (sum x1, sum x1^2, sum x2, sum x2^2) -> the sample's statistics
-__device__ __forceinline__ Moments moments_from_totals(const double (&a)[4], long n, int mode);
-// sum of the first NV entries of `nrows` rows of 4 doubles: one row per lane, then a wave reduction (every lane gets it)
-template <int NV>
-__device__ __forceinline__ void sum_rows(const double* rows, int nrows, double (&a)[NV]) {
-#pragma unroll
-  for (int k = 0; k < NV; ++k) a[k] = 0.0;
-  for (int r = threadIdx.x & 63; r < nrows; r += 64) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) a[k] += rows[4 * r + k];
-  }
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_xor(a[k], off, 64);
-  }
-}
-__device__ __forceinline__ Moments moments_of(const double* rows, int nrows, long n, int mode) {
-  double a[4];
-  sum_rows<4>(rows, nrows, a);
-  return moments_from_totals(a, n, mode);
-}
-__device__ __forceinline__ Moments moments_from_totals(const double (&a)[4], long n, int mode) {
-  const double dn = (double)n;
-  const double m1 = a[0] / dn, m2 = a[2] / dn;
-  double mu, var;
-  if (mode == ARFLOW_FEATNORM_JOINT) {
-    const double N = 2.0 * dn;
-    mu = (a[0] + a[2]) / N;
-    var = ((a[1] + a[3]) - N * mu * mu) / (N - 1.0);
-  } else {
-    mu = 0.5 * (m1 + m2);
-    var = 0.5 * ((a[1] - dn * m1 * m1) + (a[3] - dn * m2 * m2)) / (dn - 1.0);
-  }
-  var = var > 0.0 ? var : 0.0;
-  Moments m;
-  m.m1 = (float)m1, m.m2 = (float)m2, m.mu = (float)mu, m.var = (float)var;
-  m.rstd = 0.f;
-  return m;
+  featnorm::block_sum_f64<NV, NTH>(v, scratch);
 }
 
 // grid (blocks per sample, B).  acc[b] += (sum x1, sum x1^2, sum x2, sum x2^2) of this block's slice.
@@ -354,13 +295,7 @@ __global__ __launch_bounds__(NTS) void bwd_small_kernel(const float* __restrict_
   }
 }
 
-// enough workgroups to fill the chip (~2048) without slicing a sample finer than one trip per block
-inline unsigned blocks_per_sample(int B, long n, int floats_per_block) {
-  long nb = (n + floats_per_block - 1) / floats_per_block;
-  const long want = (2048 + B - 1) / B;
-  if (nb > want) nb = want;
-  return (unsigned)(nb < 1 ? 1 : nb);
-}
+inline unsigned blocks_per_sample(int B, long n, int floats_per_block) { return af_blocks_per_sample(B, n, floats_per_block); }
 
 }  // namespace
 
@@ -411,5 +346,18 @@ extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float
   AF_LAUNCH_CHECK();
   hipLaunchKernelGGL(bwd_apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
                      (int)rows, gx1, gx2, n, mode);
+  return af_launch_status();
+}
+
+// Level without a warp (the coarsest one, models/pwclite_uflow.py:206-207): the moment pass alone, rows in the layout
+// the level correlation reads (arflow_level_acc_rows(..., has_flow = 0) rows per sample).
+extern "C" int arflow_level_moments(const float* x1, const float* x2, double* acc, int B, long n, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE_PTR(acc);
+  AF_REQUIRE(B > 0 && B <= 65535 && n >= 2, ARFLOW_ESHAPE);
+  const unsigned rows = blocks_per_sample(B, n, NT * VPT);
+  hipLaunchKernelGGL(moment_kernel, dim3(rows, B), dim3(NT), 0, (hipStream_t)stream, x1, x2, acc, n);
   return af_launch_status();
 }

@@ -10,6 +10,7 @@
 // the compulsory 4*px*(2C+2) bytes forward, 4*px*(3C+4) backward.
 #include "common.hpp"
 #include "taps.hpp"
+#include "featnorm_stats.hpp"
 
 namespace {
 
@@ -88,19 +89,37 @@ __device__ __forceinline__ void window_store(float* __restrict__ win, const floa
       if (pl.ok[it] && c0 + c < C) *reinterpret_cast<float4*>(win + c * HMAX * WP + pl.dst[it]) = v[c][it];
 }
 
-template <int WQ, int CCH, typename TS>  // window row = WQ float4
+// MOM: also accumulate this thread's share of the moments the feature normalisation needs -- (sum, sum of squares) of
+// the first feature map at the thread's pixel (`x1p`, read one chunk ahead like the window) and of the warped values
+// it has just produced -- into mom[0..3] (fp32 over <= C values per thread; the caller continues in double).
+template <int WQ, int CCH, typename TS, bool MOM = false>  // window row = WQ float4
 __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restrict__ sp, float* __restrict__ op,
                                     const TapPlan& p, bool inside, int C, int ss, int os, int Ws, int ax0, int by0,
-                                    int bh, int l0, int l1, int l2, int l3) {
+                                    int bh, int l0, int l1, int l2, int l3, const float* __restrict__ x1p = nullptr,
+                                    float* mom = nullptr) {
   constexpr int WP = 4 * WQ;
   const WindowPlan<WQ> pl = window_plan<WQ>(Ws, ax0, by0, bh);
   float4 v[CCH][WindowPlan<WQ>::ITER];
+  float xn[CCH];
+  auto fetch_x1 = [&](int cc) {
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) xn[c] = (MOM && inside && cc + c < C) ? x1p[(long)(cc + c) * os] : 0.f;
+  };
   const int step = gridDim.y * CCH;  // channels are independent: at small levels they are spread over gridDim.y workgroups
   int c0 = blockIdx.y * CCH;
-  if (c0 < C) window_load<WQ, CCH, TS>(v, pl, sp, c0, C, ss);
+  if (c0 < C) {
+    if (MOM) fetch_x1(c0);
+    window_load<WQ, CCH, TS>(v, pl, sp, c0, C, ss);
+  }
   for (; c0 < C; c0 += step) {
+    float xa[CCH];
+#pragma unroll
+    for (int c = 0; c < CCH; ++c) xa[c] = MOM ? xn[c] : 0.f;
     window_store<WQ, CCH>(win, v, pl, c0, C);
-    if (c0 + step < C) window_load<WQ, CCH, TS>(v, pl, sp, c0 + step, C, ss);  // next chunk: in flight during this one
+    if (c0 + step < C) {  // next chunk: in flight during this one
+      if (MOM) fetch_x1(c0 + step);
+      window_load<WQ, CCH, TS>(v, pl, sp, c0 + step, C, ss);
+    }
     __syncthreads();
     if (inside) {
 #pragma unroll
@@ -112,6 +131,10 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
           r = p.ok[2] ? fmaf(w[l2], p.w[2], r) : r;
           r = p.ok[3] ? fmaf(w[l3], p.w[3], r) : r;
           op[(long)(c0 + c) * os] = r;
+          if (MOM) {
+            mom[0] += xa[c], mom[1] = fmaf(xa[c], xa[c], mom[1]);
+            mom[2] += r, mom[3] = fmaf(r, r, mom[3]);
+          }
         }
       }
     }
@@ -222,6 +245,155 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const TS* __restrict__ sr
       r = p.ok[3] ? fmaf(a[u][3], p.w[3], r) : r;
       if (c0 + u < C) op[(long)(c0 + u) * os] = r;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level forward, first launch: everything a pyramid level does in front of its cost volume
+// (models/pwclite_uflow.py:203-214, models/uflow_model.py:160-172) in ONE pass --
+//   UP:  flow = interpolate(flow_coarse * 2, x2, bilinear)   (ATen upsample_bilinear2d arithmetic, either align flag),
+//        written to `flow_up` and (optionally) into its slot of the decoder's concatenated input `flow_up2`;
+//   x2w = bilinear warp of the second feature map by that flow (the warp_fwd_kernel above, same LDS window);
+//   the partial moments of normalize_features -- (sum x1, sum x1^2, sum x2w, sum x2w^2) of this tile -- as one row
+//   of 4 doubles per workgroup in `acc` ([B][rows][4], rows = tiles per sample x gridDim.y), which the correlation
+//   launch folds into its epilogue: the normalised maps are never written (the moment pass and the apply pass of
+//   featnorm.hip and ATen's interpolate + mul launches disappear).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up2_source(int d, int n_in, int n_out, bool align, int& i0, int& i1, float& l0,
+                                           float& l1) {
+  // ATen/native/UpSample.h area_pixel_compute_source_index + the index / lambda arithmetic of upsample_bilinear2d
+  float src;
+  if (align) {
+    const float scale = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+    src = scale * (float)d;
+  } else {
+    src = 0.5f * ((float)d + 0.5f) - 0.5f;  // scale_factor = 2 given: scale = 1 / 2
+    src = src < 0.f ? 0.f : src;
+  }
+  i0 = min((int)src, n_in - 1);
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <bool UP>
+__global__ __launch_bounds__(256) void level_warp_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ src,
+                                                             const float* __restrict__ flow, float* __restrict__ flow_up,
+                                                             float* __restrict__ flow_up2, long fu2_bs,
+                                                             float* __restrict__ out, double* __restrict__ acc, int nimg,
+                                                             int C, int H, int W, long fbs, int pad, int align, int norm,
+                                                             int up_align) {
+  using namespace fwd_win;
+  constexpr int CCH = 2;
+  __shared__ __attribute__((aligned(16))) float win[CCH * HMAX * 72];
+  __shared__ int red[4][NT / 64];
+  __shared__ int box[4];
+  __shared__ double dscratch[4 * (NT / 64)];
+  int btx, bty, b;
+  const int ntx = (W + TX - 1) / TX, nty = (H + TY - 1) / TY;
+  if (!af_tile_of_block(ntx, nty, nimg, btx, bty, b)) return;
+  const int x = btx * TX + (int)(threadIdx.x & 31), y = bty * TY + (int)(threadIdx.x >> 5);
+  const bool inside = x < W && y < H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Hs = H, Ws = W;
+  Taps t = no_taps();
+  if (inside) {
+    float u, v;
+    if (UP) {
+      const int Hc = H / 2, Wc = W / 2;
+      int xa, xb, ya, yb;
+      float wx0, wx1, wy0, wy1;
+      up2_source(x, Wc, W, up_align != 0, xa, xb, wx0, wx1);
+      up2_source(y, Hc, H, up_align != 0, ya, yb, wy0, wy1);
+      const float* fc = flow + (long)b * fbs;
+      const long cs = (long)Hc * Wc;
+      const float a00 = fc[ya * Wc + xa], a01 = fc[ya * Wc + xb], a10 = fc[yb * Wc + xa], a11 = fc[yb * Wc + xb];
+      const float b00 = fc[cs + ya * Wc + xa], b01 = fc[cs + ya * Wc + xb], b10 = fc[cs + yb * Wc + xa],
+                  b11 = fc[cs + yb * Wc + xb];
+      // interpolate(2 f) = 2 interpolate(f) exactly in fp32 (a power-of-two scale commutes with every rounding)
+      u = 2.f * (wy0 * (wx0 * a00 + wx1 * a01) + wy1 * (wx0 * a10 + wx1 * a11));
+      v = 2.f * (wy0 * (wx0 * b00 + wx1 * b01) + wy1 * (wx0 * b10 + wx1 * b11));
+      if (blockIdx.y == 0) {
+        const long o = (long)y * W + x, os2 = (long)H * W;
+        if (flow_up) flow_up[(long)b * 2 * os2 + o] = u, flow_up[(long)b * 2 * os2 + os2 + o] = v;
+        if (flow_up2) flow_up2[(long)b * fu2_bs + o] = u, flow_up2[(long)b * fu2_bs + os2 + o] = v;
+      }
+    } else {
+      const float* fb = flow + (long)b * fbs + (long)y * W + x;
+      u = fb[0], v = fb[(long)H * W];
+    }
+    t = make_taps((float)x, (float)y, u, v, H, W, Hs, Ws, pad, align != 0, norm);
+  }
+  const TapPlan p = plan_taps(t, Hs, Ws);
+  const bool any = (t.vx0 || t.vx1) && (t.vy0 || t.vy1);
+  int lo_x = any ? t.x0 + (t.vx0 ? 0 : 1) : 0x7fffffff, hi_x = any ? t.x0 + (t.vx1 ? 1 : 0) : -0x7fffffff;
+  int lo_y = any ? t.y0 + (t.vy0 ? 0 : 1) : 0x7fffffff, hi_y = any ? t.y0 + (t.vy1 ? 1 : 0) : -0x7fffffff;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_x = min(lo_x, __shfl_xor(lo_x, off, 64));
+    lo_y = min(lo_y, __shfl_xor(lo_y, off, 64));
+    hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
+    hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+  }
+  if (lane == 0) red[0][wave] = lo_x, red[1][wave] = lo_y, red[2][wave] = hi_x, red[3][wave] = hi_y;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = red[0][0], bb = red[1][0], c = red[2][0], d = red[3][0];
+    for (int w = 1; w < NT / 64; ++w)
+      a = min(a, red[0][w]), bb = min(bb, red[1][w]), c = max(c, red[2][w]), d = max(d, red[3][w]);
+    box[0] = a, box[1] = bb, box[2] = c, box[3] = d;
+  }
+  __syncthreads();
+  const int bx0 = box[0], by0 = box[1];
+  const int bh = box[3] - by0 + 1;
+  const int ax0 = bx0 & ~3;
+  const int aw = box[2] - ax0 + 1;
+  const bool empty = box[2] < bx0;
+  const int ss = Hs * Ws, os = H * W;
+  const float* sp = src + (long)b * C * ss;
+  float* op = out + (long)b * C * os + (long)y * W + x;
+  const float* x1p = x1 + (long)b * C * os + (long)y * W + x;
+  float mom[4] = {0.f, 0.f, 0.f, 0.f};
+
+  if (!empty && (Ws & 3) == 0 && bh <= HMAX && aw <= 72) {
+    const int xa = min(max(t.x0, 0), Ws - 1) - ax0, xb = min(max(t.x0 + 1, 0), Ws - 1) - ax0;
+    const int ya = min(max(t.y0, 0), Hs - 1) - by0, yb = min(max(t.y0 + 1, 0), Hs - 1) - by0;
+    const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
+    const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
+    if (aw <= 48)
+      run<12, CCH, float, true>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 48 + cxa, cya * 48 + cxb,
+                                cyb * 48 + cxa, cyb * 48 + cxb, x1p, mom);
+    else
+      run<18, CCH, float, true>(win, sp, op, p, inside, C, ss, os, Ws, ax0, by0, bh, cya * 72 + cxa, cya * 72 + cxb,
+                                cyb * 72 + cxa, cyb * 72 + cxb, x1p, mom);
+  } else if (inside) {
+    // no tap of the tile inside the source (zeros out), or a window too large / unaligned rows (direct gathers)
+    for (int c = blockIdx.y * CCH; c < C; c += gridDim.y * CCH) {
+#pragma unroll
+      for (int u = 0; u < CCH; ++u) {
+        if (c + u >= C) continue;
+        float r = 0.f;
+        if (!empty) {
+          const float* s = sp + (long)(c + u) * ss;
+          const float a0 = s[p.o[0]], a1 = s[p.o[1]], a2 = s[p.o[2]], a3 = s[p.o[3]];
+          r = p.ok[0] ? a0 * p.w[0] : 0.f;
+          r = p.ok[1] ? fmaf(a1, p.w[1], r) : r;
+          r = p.ok[2] ? fmaf(a2, p.w[2], r) : r;
+          r = p.ok[3] ? fmaf(a3, p.w[3], r) : r;
+        }
+        op[(long)(c + u) * os] = r;
+        const float xv = x1p[(long)(c + u) * os];
+        mom[0] += xv, mom[1] = fmaf(xv, xv, mom[1]);
+        mom[2] += r, mom[3] = fmaf(r, r, mom[3]);
+      }
+    }
+  }
+  double dm[4] = {(double)mom[0], (double)mom[1], (double)mom[2], (double)mom[3]};
+  featnorm::block_sum_f64<4, NT>(dm, dscratch);
+  if (threadIdx.x == 0) {
+    const int rows = ntx * nty * gridDim.y;
+    double* row = acc + 4 * ((long)b * rows + (long)(bty * ntx + btx) * gridDim.y + blockIdx.y);
+    row[0] = dm[0], row[1] = dm[1], row[2] = dm[2], row[3] = dm[3];
   }
 }
 
@@ -714,13 +886,7 @@ __global__ __launch_bounds__(256) void occ_bidir_kernel(const float* __restrict_
 }
 
 inline dim3 pixel_grid(int B, int H, int W, int bx) { return dim3(af_cdiv(W, bx), H, B); }
-// Few tiles (coarse pyramid levels): spread the 4-channel chunks of a tile over up to C/4 workgroups until
-// ~2048 workgroups are in flight, instead of one workgroup walking all channels serially.
-inline unsigned channel_split(long tiles, int C) {
-  unsigned n = 1;
-  while ((long)n * 2 <= C / 4 && tiles * n * 2 <= 2048) n *= 2;
-  return n;
-}
+inline unsigned channel_split(long tiles, int C) { return af_channel_split(tiles, C); }
 inline int pick_bx(int W) { return W >= 192 ? 256 : (W >= 96 ? 128 : 64); }
 
 }  // namespace
@@ -745,6 +911,48 @@ extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, 
     hipLaunchKernelGGL(warp_fwd_kernel<2>, dim3(af_grid_for_tiles(tiles), channel_split(tiles, C)), dim3(256), 0,
                        (hipStream_t)stream, src, flow, out, valid, B, C, Hs, Ws, H, W, flow_bstride, pad_mode,
                        align_corners, norm_mode);
+  return af_launch_status();
+}
+
+// ---- level entry points: see level_warp_fwd_kernel -------------------------------------------
+extern "C" int arflow_level_acc_rows(int B, int C, int H, int W, int has_flow) {
+  if (!(B > 0 && C > 0 && H > 0 && W > 0)) return ARFLOW_ESHAPE;
+  if (has_flow) {
+    const long per = (long)af_cdiv(W, 32) * af_cdiv(H, 8);
+    return (int)(per * channel_split(per * B, C));
+  }
+  return (int)af_blocks_per_sample(B, (long)C * H * W, 256 * 16);
+}
+
+extern "C" int arflow_level_warp_fwd(const float* x1, const float* x2, const float* flow, long flow_bstride,
+                                     int flow_is_coarse, int up_align_corners, float* flow_up, float* flow_up2,
+                                     long flow_up2_bstride, float* x2w, double* acc, int B, int C, int H, int W,
+                                     int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(x2w);
+  AF_REQUIRE_PTR(acc);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode == ARFLOW_NORM_ARFLOW || norm_mode == ARFLOW_NORM_UFLOW, ARFLOW_EPARAM);
+  if (flow_is_coarse) {
+    AF_REQUIRE(H % 2 == 0 && W % 2 == 0 && H >= 2 && W >= 2, ARFLOW_ESHAPE);
+    AF_REQUIRE(flow_bstride >= 2L * (H / 2) * (W / 2), ARFLOW_ESHAPE);
+    AF_REQUIRE(flow_up2 == nullptr || flow_up2_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  } else {
+    AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  }
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  const dim3 grid(af_grid_for_tiles(tiles), channel_split(tiles, C));
+  if (flow_is_coarse)
+    hipLaunchKernelGGL(level_warp_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, flow, flow_up, flow_up2,
+                       flow_up2_bstride, x2w, acc, B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode,
+                       up_align_corners);
+  else
+    hipLaunchKernelGGL(level_warp_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, flow, nullptr, nullptr,
+                       0L, x2w, acc, B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode, 0);
   return af_launch_status();
 }
 

@@ -379,6 +379,167 @@ def normalize_pair(x1, x2, mode='joint'):
 
 
 # ------------------------------------------------------------------------------------------------
+class LevelCfg:
+    """Static description of one fused pyramid level (not a tensor: travels through autograd as a plain argument).
+
+    layout: the channel order of the decoder's concatenated input as a list of 'vol' (cost volume + LeakyReLU), 'x1n'
+    (normalised first map), 'flow' (the x2-upsampled flow, only with a coarse flow) and integers (index into the extra
+    member tensors)."""
+
+    def __init__(self, layout, norm_mode, slope=0.1, max_displacement=4, flow_is_coarse=True, up_align_corners=True,
+                 pad='zeros', align_corners=True, coord_norm=NORM_ARFLOW):
+        self.layout = list(layout)
+        self.mode = FEATNORM[norm_mode]
+        self.slope, self.d = float(slope), int(max_displacement)
+        self.flow_is_coarse, self.up_align = bool(flow_is_coarse), bool(up_align_corners)
+        self.pad, self.align, self.norm = PAD[pad], int(bool(align_corners)), int(coord_norm)
+
+
+def level_supported(x1, flow, flow_is_coarse, max_displacement=4):
+    """The fused level launches take the shapes of the tuned correlation kernels (W % 4 == 0, C % 4 == 0, d = 4)."""
+    B, C, H, W = x1.shape
+    if not (x1.is_cuda and x1.dtype == torch.float32 and _LEVEL_FUSED):
+        return False
+    if not _lib.load().arflow_corr_strided_supported(int(C), int(W), int(max_displacement)):
+        return False
+    if flow is not None and flow_is_coarse and (H % 2 or W % 2 or tuple(flow.shape[2:]) != (H // 2, W // 2)):
+        return False
+    return True
+
+
+_LEVEL_FUSED = __import__('os').environ.get('ARFLOW_LEVEL_FUSED', '1') != '0'  # A/B switch for tools/ and tests
+
+
+class LevelFunction(torch.autograd.Function):
+    """One pyramid level in front of its flow estimator (models/pwclite_uflow.py:203-222,
+    models/uflow_model.py:160-198):
+
+        flow_up = interpolate(flow * 2, x2)                 (flow_is_coarse)
+        x2w     = warp(x2, flow_up)                         (no flow: x2w = x2)
+        x1n, x2n = normalize_features([x1, x2w])
+        buf     = cat([..., leaky_relu(corr(x1n, x2n)), x1n, flow_up, ...], 1)
+
+    forward = arflow_level_warp_fwd (or arflow_level_moments) + arflow_level_corr_fwd: the normalised second map, the
+    moment / apply passes of the normalisation and the interpolate / mul / cat launches do not exist.  Returns
+    (buf, flow_up) with a coarse flow, else buf."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, flow, cfg, *members):
+        _need_gpu(x1, x2, flow, *members)
+        if x1.shape != x2.shape or x1.dim() != 4:
+            raise ValueError('level expects two [B,C,H,W] feature maps of equal shape')
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, C, H, W = x1.shape
+        lib = _lib.load()
+        nvol = (2 * cfg.d + 1) ** 2
+        has_flow = flow is not None
+        chans, offs, off = [], {}, 0
+        for item in cfg.layout:
+            c = {'vol': nvol, 'x1n': C, 'flow': 2}[item] if isinstance(item, str) else int(members[item].shape[1])
+            offs[item] = off
+            chans.append(c)
+            off += c
+        ctot = off
+        if 'flow' in offs and not (has_flow and cfg.flow_is_coarse):
+            raise ValueError("layout item 'flow' needs a coarse flow")
+        buf = torch.empty(B, ctot, H, W, device=x1.device, dtype=torch.float32)
+        bs = ctot * H * W
+        rows = lib.arflow_level_acc_rows(B, C, H, W, int(has_flow))
+        acc = torch.empty(4 * B * rows, device=x1.device, dtype=torch.float64)
+        stats = torch.empty(B, 4, device=x1.device, dtype=torch.float32)
+        sign = torch.empty(B, 3, H, W, device=x1.device, dtype=torch.int32) if cfg.slope != 1.0 else None
+        flow_full = x2w = None
+        with torch.cuda.device_of(x1):
+            if has_flow:
+                flow, fbs = _flow_view(flow)
+                x2w = torch.empty_like(x2)
+                if cfg.flow_is_coarse:
+                    flow_full = torch.empty(B, 2, H, W, device=x1.device, dtype=torch.float32)
+                    fslot = buf[:, offs['flow']:].data_ptr() if 'flow' in offs else None
+                    _call('arflow_level_warp_fwd', _p(x1), _p(x2), _p(flow), fbs, 1, int(cfg.up_align), _p(flow_full), fslot,
+                          bs, _p(x2w), _p(acc), B, C, H, W, cfg.pad, cfg.align, cfg.norm, _stream(), key=(B, C, H, W, 1))
+                else:
+                    flow_full = flow
+                    _call('arflow_level_warp_fwd', _p(x1), _p(x2), _p(flow), fbs, 0, 0, None, None, 0, _p(x2w), _p(acc),
+                          B, C, H, W, cfg.pad, cfg.align, cfg.norm, _stream(), key=(B, C, H, W, 0))
+            else:
+                _call('arflow_level_moments', _p(x1), _p(x2), _p(acc), B, C * H * W, _stream(), key=(B, C * H * W))
+            if 'x1n' in offs:
+                x1n, x1n_ptr, x1n_bs = None, buf[:, offs['x1n']:].data_ptr(), bs
+            else:
+                x1n = torch.empty_like(x1)
+                x1n_ptr, x1n_bs = x1n.data_ptr(), C * H * W
+            _call('arflow_level_corr_fwd', _p(x1), _p(x2w if has_flow else x2), _p(acc), rows, cfg.mode,
+                  buf[:, offs['vol']:].data_ptr(), bs, x1n_ptr, x1n_bs, _p(sign), _p(stats), B, C, H, W, cfg.d, cfg.slope,
+                  _stream(), key=(B, C, H, W, cfg.d, 3 if sign is not None else 0))
+        for item in cfg.layout:
+            if not isinstance(item, str):
+                buf[:, offs[item]:offs[item] + int(members[item].shape[1])].copy_(members[item])
+        ctx.save_for_backward(x1, x2, x2w, flow_full, stats, sign, buf if x1n is None else x1n)
+        ctx.cfg, ctx.offs, ctx.ctot, ctx.n_members, ctx.has_flow = cfg, offs, ctot, len(members), has_flow
+        ctx.member_chans = [int(m.shape[1]) for m in members]
+        if has_flow and cfg.flow_is_coarse:
+            return buf, flow_full
+        return buf
+
+    @staticmethod
+    def backward(ctx, gbuf, gflow_ext=None):
+        x1, x2, x2w, flow_full, stats, sign, x1n_holder = ctx.saved_tensors
+        cfg, offs, ctot = ctx.cfg, ctx.offs, ctx.ctot
+        B, C, H, W = x1.shape
+        nvol = (2 * cfg.d + 1) ** 2
+        gbuf = gbuf.contiguous()
+        bs = ctot * H * W
+        if 'x1n' in offs:
+            x1n_ptr, x1n_bs = x1n_holder[:, offs['x1n']:].data_ptr(), bs
+        else:
+            x1n_ptr, x1n_bs = x1n_holder.data_ptr(), C * H * W
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x1)
+        d1, d2 = torch.empty_like(x1), torch.empty_like(x1)
+        acc = _featnorm_acc(B, x1.device)
+        gx2 = gflow_in = None
+        with torch.cuda.device_of(x1):
+            _call('arflow_level_corr_bwd', gbuf[:, offs['vol']:].data_ptr(), bs, _p(sign), x1n_ptr, x1n_bs,
+                  _p(x2w if ctx.has_flow else x2), _p(stats), _p(g1), _p(g2), B, C, H, W, cfg.d, cfg.slope, _stream(),
+                  key=(B, C, H, W, cfg.d, 3 if sign is not None else 0))
+            if 'x1n' in offs:
+                g1 = g1 + gbuf[:, offs['x1n']:offs['x1n'] + C]
+            n = C * H * W
+            _call('arflow_featnorm_bwd', _p(g1), _p(g2), _p(x1), _p(x2w if ctx.has_flow else x2), _p(stats), _p(acc), _p(d1),
+                  _p(d2), B, n, cfg.mode, _stream(), key=(B, n))
+            if ctx.has_flow:
+                gx2 = torch.empty_like(x2)
+                gfl = torch.empty(B, 2, H, W, device=x1.device, dtype=torch.float32)
+                fl, fbs = _flow_view(flow_full)
+                _call('arflow_warp_bwd', _p(d2), _p(x2), _p(fl), _p(gx2), _p(gfl), B, C, H, W, H, W, fbs, cfg.pad, cfg.align,
+                      cfg.norm, _stream(), key=(B, C, H, W, True))
+                if cfg.flow_is_coarse:
+                    if 'flow' in offs:
+                        gfl = gfl + gbuf[:, offs['flow']:offs['flow'] + 2]
+                    if gflow_ext is not None:
+                        gfl = gfl + gflow_ext
+                    # interpolate(2 f) backward: the adjoint of ATen's bilinear upsample, times 2
+                    gflow_in = torch.ops.aten.upsample_bilinear2d_backward(gfl, [H, W], [B, 2, H // 2, W // 2], cfg.up_align,
+                                                                           2.0, 2.0) * 2.0
+                else:
+                    gflow_in = gfl
+            else:
+                gx2 = d2
+        gm, k = [], 0
+        for item in cfg.layout:
+            if not isinstance(item, str):
+                gm.append((item, gbuf[:, offs[item]:offs[item] + ctx.member_chans[item]]))
+        gmembers = [None] * ctx.n_members
+        for idx, g in gm:
+            gmembers[idx] = g if ctx.needs_input_grad[4 + idx] else None
+        return (d1, gx2, gflow_in, None) + tuple(gmembers)
+
+
+def level(x1, x2, flow, cfg, *members):
+    return LevelFunction.apply(x1, x2, flow, cfg, *members)
+
+
+# ------------------------------------------------------------------------------------------------
 class BiasLeakyReLUFunction(torch.autograd.Function):
     """y = leaky_relu(x + bias[None, :, None, None], slope), IN PLACE on x (the bias-free output of a
     convolution, which autograd does not need again); backward = LeakyReLU derivative and bias gradient in

@@ -82,17 +82,30 @@ class PWCLiteUflow(nn.Module):
         act = None
         levels = list(zip(x1_pyramid[0:self.output_level + 1], x2_pyramid[0:self.output_level + 1]))
         for l, (x1, x2) in enumerate(levels):
-            if l == 0:
-                x2_warp = x2
+            if (self.feature_norm and self.feature_storage is None
+                    and AF.level_supported(x1, None if l == 0 else flow, True, self.search_range)):
+                # the whole level in front of the estimator as two launches: flow upsample +
+                # warp + moments, then the cost volume of the normalised pair straight from the raw maps
+                if l == 0:
+                    cfg = AF.LevelCfg(['vol', 'x1n', 0], 'joint', 0.1, self.search_range)
+                    est_in = AF.level(x1, x2, None, cfg, flow)
+                else:
+                    cfg = AF.LevelCfg(['vol', 'x1n', 'flow', 0], 'joint', 0.1, self.search_range, True, self.align_corners,
+                                      self.warp_pad, self.align_corners)
+                    est_in, flow = AF.level(x1, x2, flow, cfg, self.deconv_networks[l - 1](act))
             else:
-                flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=self.align_corners)
-                x2_warp = flow_warp(x2, flow, align_corners=self.align_corners, pad=self.warp_pad,
-                                    **({'storage_dtype': self.feature_storage} if self.feature_storage is not None else {}))
-            if self.feature_norm:
-                x1, x2_warp = normalize_features([x1, x2_warp])
-            # corr + LeakyReLU(0.1) in one kernel, written straight into the estimator's concatenated input
-            after = (x1, flow) if l == 0 else (x1, flow, self.deconv_networks[l - 1](act))
-            act, flow_res = self.flow_estimators[l](self.corr.concat(x1, x2_warp, after=after, negative_slope=0.1))
+                if l == 0:
+                    x2_warp = x2
+                else:
+                    flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=self.align_corners)
+                    x2_warp = flow_warp(x2, flow, align_corners=self.align_corners, pad=self.warp_pad,
+                                        **({'storage_dtype': self.feature_storage} if self.feature_storage is not None else {}))
+                if self.feature_norm:
+                    x1, x2_warp = normalize_features([x1, x2_warp])
+                # corr + LeakyReLU(0.1) in one kernel, written straight into the estimator's concatenated input
+                after = (x1, flow) if l == 0 else (x1, flow, self.deconv_networks[l - 1](act))
+                est_in = self.corr.concat(x1, x2_warp, after=after, negative_slope=0.1)
+            act, flow_res = self.flow_estimators[l](est_in)
             if drops is not None:
                 flow_res = flow_res * drops[l]
                 act = act * drops[l]

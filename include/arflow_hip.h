@@ -127,6 +127,41 @@ int arflow_featnorm_bwd(const float* g1, const float* g2, const float* x1, const
                         const float* stats, double* acc, float* gx1, float* gx2, int B, long n, int mode,
                         arflow_stream_t stream);
 
+/* ---- pyramid level, fused --------------------------------------------------------------------
+ * One level of the PWC decoders in front of its flow estimator,
+ *     flow   = interpolate(flow_coarse * 2, x2, bilinear)                 models/pwclite_uflow.py:208
+ *     x2w    = flow_warp(x2, flow)  /  resample(x2, flow_to_warp(flow))   models/pwclite_uflow.py:209, uflow_model.py:164
+ *     x1n, x2n = normalize_features([x1, x2w])                            models/pwclite_uflow.py:212-213, uflow_model.py:167-172
+ *     vol    = LeakyReLU(corr(x1n, x2n))                                  models/pwclite_uflow.py:214-215, uflow_model.py:174-178
+ * as TWO launches forward: (1) arflow_level_warp_fwd -- flow upsample + warp + the partial moments of the
+ * normalisation (one row of 4 doubles per workgroup: sum x1, sum x1^2, sum x2w, sum x2w^2); at the level without a
+ * flow arflow_level_moments takes its place; (2) arflow_level_corr_fwd -- the cost volume of the NORMALISED pair
+ * computed from the raw maps (x1 is normalised in registers, the second map's normalisation is an epilogue term),
+ * writing the volume, the normalised first map (the decoder concatenates it) and the sign words of the fused LeakyReLU.
+ * The normalised second map, the moment / apply passes and the interpolate / mul launches do not exist.
+ *
+ * acc: 4 * B * arflow_level_acc_rows(B, C, H, W, has_flow) doubles (not initialised by the caller).
+ * flow: [B,2,H/2,W/2] with flow_is_coarse (upsampled x2 inside, align flag up_align_corners; flow_up [B,2,H,W] and /
+ * or flow_up2 (batch stride flow_up2_bstride) receive it) or [B,2,H,W]; flow_bstride = floats between samples.
+ * out / x1n: volume and normalised first map with batch strides (slots of a concatenated buffer); stats: [B,4]
+ * (m1, m2, mu, sigma).  Needs the fast-path shapes (arflow_corr_strided_supported). */
+int arflow_level_acc_rows(int B, int C, int H, int W, int has_flow);
+int arflow_level_moments(const float* x1, const float* x2, double* acc, int B, long n, arflow_stream_t stream);
+int arflow_level_warp_fwd(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                          int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
+                          double* acc, int B, int C, int H, int W, int pad_mode, int align_corners, int norm_mode,
+                          arflow_stream_t stream);
+int arflow_level_corr_fwd(const float* x1, const float* x2w, const double* acc, int acc_rows, int norm_mode, float* out,
+                          long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits, float* stats, int B, int C,
+                          int H, int W, int max_disp, float negative_slope, arflow_stream_t stream);
+/* Backward of arflow_level_corr_fwd w.r.t. the NORMALISED maps: gx1n = d/d x1n (correlation part only: the caller adds the
+ * gradient the decoder's concatenation returns for x1n), gx2n = d/d x2n; x1n as written by the forward (batch stride),
+ * x2w the raw warped map, stats as written by the forward.  The normalisation's own backward is arflow_featnorm_bwd on
+ * (gx1n + direct, gx2n, x1, x2w).  sign_bits NULL <=> negative_slope == 1. */
+int arflow_level_corr_bwd(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
+                          long x1n_bstride, const float* x2w, const float* stats, float* gx1n, float* gx2n, int B, int C,
+                          int H, int W, int max_disp, float negative_slope, arflow_stream_t stream);
+
 /* ---- conv epilogue of the host models ------------------------------------------------------------
  * y = lrelu(x + bias[c]) for x, y: [B, C, HW] (x == y allowed; bias nullable): the bias add and
  * LeakyReLU(0.1) that follow every convolution of the reference models (models/pwclite.py:10-23,
