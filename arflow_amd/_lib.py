@@ -39,6 +39,10 @@ PROTOTYPES = {
     'arflow_corr_general_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
     'arflow_featnorm_fwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
     'arflow_featnorm_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_l, c_i, c_fp],
+    'arflow_level_supported': [c_i, c_i, c_i],
+    'arflow_level_bwd_ws_bytes': [c_i, c_i, c_i, c_i],
+    'arflow_level_fwd': [c_fp, c_fp, c_fp, c_l, c_i, c_i, c_fp, c_fp, c_l, c_fp, c_i, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_fp],
+    'arflow_level_bwd': [c_fp, c_l, c_fp, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_fp, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_fp],
     'arflow_level_acc_rows': [c_i, c_i, c_i, c_i, c_i],
     'arflow_level_moments': [c_fp, c_fp, c_fp, c_i, c_l, c_fp],
     'arflow_level_warp_fwd': [c_fp, c_fp, c_fp, c_l, c_i, c_i, c_fp, c_fp, c_l, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp],
@@ -90,7 +94,7 @@ def load():
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_i
+        fn.restype = c_l if name == 'arflow_level_bwd_ws_bytes' else c_i
     lib.arflow_strerror.argtypes = [c_i]
     lib.arflow_strerror.restype = ctypes.c_char_p
     if lib.arflow_abi_version() != ABI_VERSION:

@@ -400,6 +400,21 @@ static int corr_fwd_impl(const float* x1, const float* x2, float* out, long out_
   }
 }
 
+// internal launchers for the level entry points (level.hip)
+int af_level_corr_fwd_launch(const float* x1, const float* x2w, const double* acc, int acc_rows, int norm_mode, float* out,
+                             long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits, float* stats, int B, int C,
+                             int H, int W, float negative_slope, hipStream_t st) {
+  const corr_v2::NormArgs na{acc, acc_rows, norm_mode, x1n, x1n_bstride, stats};
+  return corr_v2::launch_fwd(x1, x2w, out, sign_bits, B, C, H, W, negative_slope, st, out_bstride, &na);
+}
+int af_level_corr_bwd_launch(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
+                             long x1n_bstride, const float* x2w, const float* stats, float* gx1n, float* gx2n, int B, int C,
+                             int H, int W, float negative_slope, hipStream_t st) {
+  return corr_v2::launch_bwd(gout, nullptr, negative_slope == 1.0f ? nullptr : sign_bits, negative_slope, x1n, x2w, gx1n,
+                             gx2n, B, C, H, W, st, gout_bstride, 0, x1n_bstride, stats);
+}
+extern "C" int arflow_level_supported(int C, int W, int max_disp) { return corr_v2::eligible(C, W, max_disp) ? 1 : 0; }
+
 // Level forward, second launch: cost volume of the NORMALISED pair straight from the raw maps
 // (corr_v2::fwd_kernel<.., NORM = true>): volume (+ fused LeakyReLU and sign words) into `out`, the normalised first
 // map into `x1n` (both with a batch stride: slots of the decoder's concatenated input), the statistics into `stats`.
@@ -440,8 +455,8 @@ extern "C" int arflow_level_corr_bwd(const float* gout, long gout_bstride, const
   const long vol = (long)corr_v2::N * corr_v2::N * H * W;
   AF_REQUIRE(gout_bstride >= vol && gout_bstride % 4 == 0, ARFLOW_ESHAPE);
   AF_REQUIRE(x1n_bstride >= (long)C * H * W && x1n_bstride % 4 == 0, ARFLOW_ESHAPE);
-  return corr_v2::launch_bwd(gout, nullptr, negative_slope == 1.0f ? nullptr : sign_bits, negative_slope, x1n, x2w, gx1n,
-                             gx2n, B, C, H, W, (hipStream_t)stream, gout_bstride, 0, x1n_bstride, stats);
+  return af_level_corr_bwd_launch(gout, gout_bstride, sign_bits, x1n, x1n_bstride, x2w, stats, gx1n, gx2n, B, C, H, W,
+                                  negative_slope, (hipStream_t)stream);
 }
 
 static int corr_bwd_impl(const float* gout, long gout_bstride, const float* out, long out_bstride,

@@ -100,14 +100,25 @@ __global__ __launch_bounds__(NT) void apply_kernel(const float* __restrict__ x1,
 }
 
 // acc[b] += (sum g, sum g (x - mu)) over both tensors (entries 0, 1)
+// g1b (nullable): a second gradient of y1 that is added on load -- the slot of the decoder's concatenated input that
+// holds y1 (sample b at g1b + b * g1b_bs, n contiguous floats); saves the separate add pass.
+__device__ __forceinline__ float4 ld4_sum(const float* a, const float* b, long i) {
+  float4 v = reinterpret_cast<const float4*>(a)[i];
+  if (b) {
+    const float4 w = reinterpret_cast<const float4*>(b)[i];
+    v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+  }
+  return v;
+}
 __global__ __launch_bounds__(NT) void bwd_sum_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                      const float* __restrict__ x1, const float* __restrict__ x2,
                                                      const float* __restrict__ stats, double* __restrict__ acc,
-                                                     long n) {
+                                                     long n, const float* __restrict__ g1b, long g1b_bs) {
   __shared__ double scratch[2 * (NT / 64)];
   const int b = blockIdx.y;
   const float mu = stats[4 * b + 2];
   const long o = (long)b * n;
+  const float* gbp = g1b ? g1b + (long)b * g1b_bs : nullptr;
   double s[2] = {0.0, 0.0};
   const long n4 = (n % 4 == 0) ? n / 4 : 0;
   for (long i0 = (long)blockIdx.x * NT * (VPT / 4); i0 < n4; i0 += (long)gridDim.x * NT * (VPT / 4)) {
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(NT) void bwd_sum_kernel(const float* __restrict__ g
     for (int k = 0; k < VPT / 4; ++k) {
       const long i = i0 + (long)k * NT + threadIdx.x;
       if (i < n4) {
-        const float4 ga = reinterpret_cast<const float4*>(g1 + o)[i], xa = reinterpret_cast<const float4*>(x1 + o)[i];
+        const float4 ga = ld4_sum(g1 + o, gbp, i), xa = reinterpret_cast<const float4*>(x1 + o)[i];
         const float4 gb = reinterpret_cast<const float4*>(g2 + o)[i], xb = reinterpret_cast<const float4*>(x2 + o)[i];
         sg += ((ga.x + ga.y) + (ga.z + ga.w)) + ((gb.x + gb.y) + (gb.z + gb.w));
         sq = fmaf(ga.x, xa.x - mu, fmaf(ga.y, xa.y - mu, fmaf(ga.z, xa.z - mu, fmaf(ga.w, xa.w - mu, sq))));
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(NT) void bwd_sum_kernel(const float* __restrict__ g
     s[0] += (double)sg, s[1] += (double)sq;
   }
   for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
-    const float ga = g1[o + i], gb = g2[o + i];
+    const float ga = g1[o + i] + (gbp ? gbp[i] : 0.f), gb = g2[o + i];
     s[0] += (double)ga + (double)gb;
     s[1] += (double)ga * (double)(x1[o + i] - mu) + (double)gb * (double)(x2[o + i] - mu);
   }
@@ -144,8 +155,9 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ x1, const float* __restrict__ x2,
                                                        const float* __restrict__ stats, const double* __restrict__ acc,
                                                        int nrows, float* __restrict__ d1, float* __restrict__ d2, long n,
-                                                       int mode) {
+                                                       int mode, const float* __restrict__ g1b, long g1b_bs) {
   const int b = blockIdx.y;
+  const float* gbp = g1b ? g1b + (long)b * g1b_bs : nullptr;
   const float* st = stats + 4 * b;
   const double r = 1.0 / (double)st[3];
   double gq[2];
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
   const long n4 = (n % 4 == 0) ? n / 4 : 0;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
     if (d1) {
-      const float4 g = reinterpret_cast<const float4*>(g1 + o)[i], x = reinterpret_cast<const float4*>(x1 + o)[i];
+      const float4 g = ld4_sum(g1 + o, gbp, i), x = reinterpret_cast<const float4*>(x1 + o)[i];
       reinterpret_cast<float4*>(d1 + o)[i] = make_float4(f(g.x, x.x, c1), f(g.y, x.y, c1), f(g.z, x.z, c1), f(g.w, x.w, c1));
     }
     if (d2) {
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(NT) void bwd_apply_kernel(const float* __restrict__
     }
   }
   for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
-    if (d1) d1[o + i] = f(g1[o + i], x1[o + i], c1);
+    if (d1) d1[o + i] = f(g1[o + i] + (gbp ? gbp[i] : 0.f), x1[o + i], c1);
     if (d2) d2[o + i] = f(g2[o + i], x2[o + i], c2);
   }
 }
@@ -241,10 +253,12 @@ __global__ __launch_bounds__(NTS) void fwd_small_kernel(const float* __restrict_
 __global__ __launch_bounds__(NTS) void bwd_small_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                         const float* __restrict__ x1, const float* __restrict__ x2,
                                                         const float* __restrict__ stats, float* __restrict__ d1,
-                                                        float* __restrict__ d2, long n, int mode) {
+                                                        float* __restrict__ d2, long n, int mode,
+                                                        const float* __restrict__ g1b, long g1b_bs) {
   __shared__ double scratch[2 * (NTS / 64)];
   __shared__ double tot[2];
   const int b = blockIdx.x;
+  const float* gbp = g1b ? g1b + (long)b * g1b_bs : nullptr;
   const float* st = stats + 4 * b;
   const float mu = st[2];
   const long o = (long)b * n;
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(NTS) void bwd_small_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) {
       const long i = i0 + (long)k * NTS + threadIdx.x;
       if (i < n4) {
-        const float4 ga = reinterpret_cast<const float4*>(g1 + o)[i], xa = reinterpret_cast<const float4*>(x1 + o)[i];
+        const float4 ga = ld4_sum(g1 + o, gbp, i), xa = reinterpret_cast<const float4*>(x1 + o)[i];
         const float4 gb = reinterpret_cast<const float4*>(g2 + o)[i], xb = reinterpret_cast<const float4*>(x2 + o)[i];
         sg += ((ga.x + ga.y) + (ga.z + ga.w)) + ((gb.x + gb.y) + (gb.z + gb.w));
         sq = fmaf(ga.x, xa.x - mu, fmaf(ga.y, xa.y - mu, fmaf(ga.z, xa.z - mu, fmaf(ga.w, xa.w - mu, sq))));
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(NTS) void bwd_small_kernel(const float* __restrict_
     s[0] += (double)sg, s[1] += (double)sq;
   }
   for (long i = 4 * n4 + threadIdx.x; i < n; i += NTS) {
-    const float ga = g1[o + i], gb = g2[o + i];
+    const float ga = g1[o + i] + (gbp ? gbp[i] : 0.f), gb = g2[o + i];
     s[0] += (double)ga + (double)gb;
     s[1] += (double)ga * (double)(x1[o + i] - mu) + (double)gb * (double)(x2[o + i] - mu);
   }
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(NTS) void bwd_small_kernel(const float* __restrict_
   auto f = [&](float g, float x, float c) { return fmaf(rf, g, -cg) - cq * (x - c); };
   for (long i = threadIdx.x; i < n4; i += NTS) {
     if (d1) {
-      const float4 g = reinterpret_cast<const float4*>(g1 + o)[i], x = reinterpret_cast<const float4*>(x1 + o)[i];
+      const float4 g = ld4_sum(g1 + o, gbp, i), x = reinterpret_cast<const float4*>(x1 + o)[i];
       reinterpret_cast<float4*>(d1 + o)[i] = make_float4(f(g.x, x.x, c1), f(g.y, x.y, c1), f(g.z, x.z, c1), f(g.w, x.w, c1));
     }
     if (d2) {
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(NTS) void bwd_small_kernel(const float* __restrict_
     }
   }
   for (long i = 4 * n4 + threadIdx.x; i < n; i += NTS) {
-    if (d1) d1[o + i] = f(g1[o + i], x1[o + i], c1);
+    if (d1) d1[o + i] = f(g1[o + i] + (gbp ? gbp[i] : 0.f), x1[o + i], c1);
     if (d2) d2[o + i] = f(g2[o + i], x2[o + i], c2);
   }
 }
@@ -323,6 +337,22 @@ extern "C" int arflow_featnorm_fwd(const float* x1, const float* x2, float* y1, 
   return af_launch_status();
 }
 
+// internal launcher (also used by the level entry points, level.hip): g1b = optional second gradient of y1, added on load
+int af_featnorm_bwd_launch(const float* g1, const float* g1b, long g1b_bs, const float* g2, const float* x1, const float* x2,
+                           const float* stats, double* acc, float* gx1, float* gx2, int B, long n, int mode, hipStream_t st) {
+  if (!gx1 && !gx2) return ARFLOW_OK;
+  if (n <= SMALL_N) {
+    hipLaunchKernelGGL(bwd_small_kernel, dim3(B), dim3(NTS), 0, st, g1, g2, x1, x2, stats, gx1, gx2, n, mode, g1b, g1b_bs);
+    return af_launch_status();
+  }
+  const unsigned rows = blocks_per_sample(B, n, NT * VPT);
+  hipLaunchKernelGGL(bwd_sum_kernel, dim3(rows, B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc, n, g1b, g1b_bs);
+  AF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bwd_apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
+                     (int)rows, gx1, gx2, n, mode, g1b, g1b_bs);
+  return af_launch_status();
+}
+
 extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float* x1, const float* x2,
                                    const float* stats, double* acc, float* gx1, float* gx2, int B, long n, int mode,
                                    arflow_stream_t stream) {
@@ -335,17 +365,22 @@ extern "C" int arflow_featnorm_bwd(const float* g1, const float* g2, const float
   AF_REQUIRE_PTR(acc);
   AF_REQUIRE(B > 0 && B <= 65535 && n >= 2, ARFLOW_ESHAPE);
   AF_REQUIRE(mode == ARFLOW_FEATNORM_JOINT || mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
-  if (!gx1 && !gx2) return ARFLOW_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (n <= SMALL_N) {
-    hipLaunchKernelGGL(bwd_small_kernel, dim3(B), dim3(NTS), 0, st, g1, g2, x1, x2, stats, gx1, gx2, n, mode);
-    return af_launch_status();
-  }
+  return af_featnorm_bwd_launch(g1, nullptr, 0, g2, x1, x2, stats, acc, gx1, gx2, B, n, mode, (hipStream_t)stream);
+}
+
+// apply pass alone: the two sums come as rows of 4 doubles ([B][nrows][4]: sum g, sum g (x - mu)) left by the level
+// correlation backward (corr_v2::bwd_kernel<.., SUMS>)
+int af_featnorm_bwd_apply_launch(const float* g1, const float* g1b, long g1b_bs, const float* g2, const float* x1,
+                                 const float* x2, const float* stats, const double* rows, int nrows, float* gx1, float* gx2,
+                                 int B, long n, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(bwd_apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, rows,
+                     nrows, gx1, gx2, n, mode, g1b, g1b_bs);
+  return af_launch_status();
+}
+
+int af_featnorm_moments_launch(const float* x1, const float* x2, double* acc, int B, long n, hipStream_t st) {
   const unsigned rows = blocks_per_sample(B, n, NT * VPT);
-  hipLaunchKernelGGL(bwd_sum_kernel, dim3(rows, B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc, n);
-  AF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bwd_apply_kernel, dim3(blocks_per_sample(B, n, NT * 4), B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc,
-                     (int)rows, gx1, gx2, n, mode);
+  hipLaunchKernelGGL(moment_kernel, dim3(rows, B), dim3(NT), 0, st, x1, x2, acc, n);
   return af_launch_status();
 }
 
@@ -357,7 +392,5 @@ extern "C" int arflow_level_moments(const float* x1, const float* x2, double* ac
   AF_REQUIRE_PTR(x2);
   AF_REQUIRE_PTR(acc);
   AF_REQUIRE(B > 0 && B <= 65535 && n >= 2, ARFLOW_ESHAPE);
-  const unsigned rows = blocks_per_sample(B, n, NT * VPT);
-  hipLaunchKernelGGL(moment_kernel, dim3(rows, B), dim3(NT), 0, (hipStream_t)stream, x1, x2, acc, n);
-  return af_launch_status();
+  return af_featnorm_moments_launch(x1, x2, acc, B, n, (hipStream_t)stream);
 }

@@ -1,0 +1,140 @@
+// One pyramid level of the PWC decoders in front of its flow estimator as ONE C-ABI call per direction
+// (models/pwclite_uflow.py:203-222, models/uflow_model.py:160-198):
+//
+//     flow   = interpolate(flow_coarse * 2, x2, bilinear)                  (flow_is_coarse)
+//     x2w    = flow_warp(x2, flow)   /   resample(x2, flow_to_warp(flow))  (no flow: x2w = x2)
+//     x1n, x2n = normalize_features([x1, x2w])
+//     vol    = LeakyReLU(corr(x1n, x2n))        -> written with x1n and flow into the decoder's concatenated input
+//
+// forward  = [level_warp_fwd_kernel | moment_kernel] -> corr_v2::fwd_kernel<.., NORM>       (2 launches, no host gap)
+// backward = corr_v2::bwd_kernel<.., NORM> -> featnorm sums + apply (the concatenation's gradient of x1n added on load)
+//            -> warp backward (the concatenation's / residual's gradients of the flow added on the way out)
+//            -> adjoint of the x2 upsample.
+// The reference runs ~25 ATen kernels forward and ~60 backward per level for this.
+#include "common.hpp"
+#include "level_internal.hpp"
+
+namespace {
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct BwdWs {
+  size_t g1, g2, d2, gfl, acc, total;
+};
+inline BwdWs bwd_layout(int B, int C, int H, int W) {
+  BwdWs w;
+  const size_t n = align256(sizeof(float) * (size_t)B * C * H * W);
+  w.g1 = 0;
+  w.g2 = n;
+  w.d2 = 2 * n;
+  w.gfl = 3 * n;
+  w.acc = w.gfl + align256(sizeof(float) * (size_t)B * 2 * H * W);
+  w.total = w.acc + align256(sizeof(double) * (size_t)ARFLOW_FEATNORM_ACC_DOUBLES(B));
+  return w;
+}
+}  // namespace
+
+extern "C" int arflow_level_supported(int C, int W, int max_disp);
+
+extern "C" long arflow_level_bwd_ws_bytes(int B, int C, int H, int W) {
+  if (!(B > 0 && C > 0 && H > 0 && W > 0)) return ARFLOW_ESHAPE;
+  return (long)bwd_layout(B, C, H, W).total;
+}
+
+extern "C" int arflow_level_fwd(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                                int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
+                                int norm_mode, float* out, long out_bstride, float* x1n, long x1n_bstride,
+                                unsigned* sign_bits, float* stats, double* acc, int B, int C, int H, int W, int max_disp,
+                                float negative_slope, int pad_mode, int align_corners, int coord_norm,
+                                arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE_PTR(stats);
+  AF_REQUIRE_PTR(acc);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(arflow_level_supported(C, W, max_disp), ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode == ARFLOW_FEATNORM_JOINT || norm_mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
+  AF_REQUIRE(out_bstride >= 81L * H * W && out_bstride % 4 == 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(x1n == nullptr || (x1n_bstride >= (long)C * H * W && x1n_bstride % 4 == 0), ARFLOW_ESHAPE);
+  AF_REQUIRE(negative_slope == 1.0f || sign_bits != nullptr, ARFLOW_ENULL);
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = arflow_level_acc_rows(B, C, H, W, flow != nullptr);
+  if (flow) {
+    AF_REQUIRE_PTR(x2w);
+    AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+    AF_REQUIRE(coord_norm == ARFLOW_NORM_ARFLOW || coord_norm == ARFLOW_NORM_UFLOW, ARFLOW_EPARAM);
+    if (flow_is_coarse) {
+      AF_REQUIRE(H % 2 == 0 && W % 2 == 0, ARFLOW_ESHAPE);
+      AF_REQUIRE(flow_bstride >= 2L * (H / 2) * (W / 2), ARFLOW_ESHAPE);
+      AF_REQUIRE(flow_up2 == nullptr || flow_up2_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+    } else {
+      AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+    }
+    const int rc = af_level_warp_fwd_launch(x1, x2, flow, flow_bstride, flow_is_coarse, up_align_corners, flow_up, flow_up2,
+                                            flow_up2_bstride, x2w, acc, B, C, H, W, pad_mode, align_corners, coord_norm, st);
+    if (rc != ARFLOW_OK) return rc;
+  } else {
+    const int rc = af_featnorm_moments_launch(x1, x2, acc, B, (long)C * H * W, st);
+    if (rc != ARFLOW_OK) return rc;
+  }
+  return af_level_corr_fwd_launch(x1, flow ? x2w : x2, acc, rows, norm_mode, out, out_bstride, x1n, x1n_bstride,
+                                  negative_slope == 1.0f ? nullptr : sign_bits, stats, B, C, H, W, negative_slope, st);
+}
+
+extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
+                                long x1n_bstride, const float* gx1n_direct, long gx1n_direct_bstride, const float* x1,
+                                const float* x2, const float* x2w, const float* flow_full, long flow_bstride,
+                                const float* gflow_a, long gflow_a_bstride, const float* gflow_b, const float* stats,
+                                int norm_mode, float* gx1, float* gx2, float* gflow, int flow_is_coarse,
+                                int up_align_corners, void* workspace, int B, int C, int H, int W, int max_disp,
+                                float negative_slope, int pad_mode, int align_corners, int coord_norm,
+                                arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gout);
+  AF_REQUIRE_PTR(x1n);
+  AF_REQUIRE_PTR(x1);
+  AF_REQUIRE_PTR(x2);
+  AF_REQUIRE_PTR(stats);
+  AF_REQUIRE_PTR(gx1);
+  AF_REQUIRE_PTR(gx2);
+  AF_REQUIRE_PTR(workspace);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(arflow_level_supported(C, W, max_disp), ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode == ARFLOW_FEATNORM_JOINT || norm_mode == ARFLOW_FEATNORM_AVG, ARFLOW_EPARAM);
+  AF_REQUIRE(gout_bstride >= 81L * H * W && gout_bstride % 4 == 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(x1n_bstride >= (long)C * H * W && x1n_bstride % 4 == 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(gx1n_direct == nullptr || (gx1n_direct_bstride >= (long)C * H * W && gx1n_direct_bstride % 4 == 0), ARFLOW_ESHAPE);
+  AF_REQUIRE(negative_slope == 1.0f || sign_bits != nullptr, ARFLOW_ENULL);
+  AF_REQUIRE(((size_t)workspace & 255) == 0, ARFLOW_EPARAM);
+  hipStream_t st = (hipStream_t)stream;
+  const BwdWs ws = bwd_layout(B, C, H, W);
+  char* base = (char*)workspace;
+  float* g1 = (float*)(base + ws.g1);
+  float* g2 = (float*)(base + ws.g2);
+  float* d2 = (float*)(base + ws.d2);
+  float* gfl = (float*)(base + ws.gfl);
+  double* acc = (double*)(base + ws.acc);
+  const bool has_flow = flow_full != nullptr;
+  if (has_flow) {
+    AF_REQUIRE_PTR(x2w);
+    AF_REQUIRE_PTR(gflow);
+    AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+    AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+    AF_REQUIRE(coord_norm == ARFLOW_NORM_ARFLOW || coord_norm == ARFLOW_NORM_UFLOW, ARFLOW_EPARAM);
+    AF_REQUIRE(!flow_is_coarse || (H % 2 == 0 && W % 2 == 0), ARFLOW_ESHAPE);
+    AF_REQUIRE(gflow_a == nullptr || gflow_a_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  }
+  const float* second = has_flow ? x2w : x2;
+  int rc = af_level_corr_bwd_launch(gout, gout_bstride, sign_bits, x1n, x1n_bstride, second, stats, g1, g2, B, C, H, W,
+                                    negative_slope, st);
+  if (rc != ARFLOW_OK) return rc;
+  // the normalisation's backward (the concatenation's gradient of x1n added on load); without a warp its second
+  // output IS d/d x2
+  rc = af_featnorm_bwd_launch(g1, gx1n_direct, gx1n_direct_bstride, g2, x1, second, stats, acc, gx1, has_flow ? d2 : gx2, B,
+                              (long)C * H * W, norm_mode, st);
+  if (rc != ARFLOW_OK || !has_flow) return rc;
+  rc = af_warp_bwd_launch(d2, x2, flow_full, gx2, flow_is_coarse ? gfl : gflow, B, C, H, W, H, W, flow_bstride, pad_mode,
+                          align_corners, coord_norm, gflow_a, gflow_a_bstride, gflow_b, st);
+  if (rc != ARFLOW_OK || !flow_is_coarse) return rc;
+  return af_up2_bwd_launch(gfl, gflow, B * 2, H, W, up_align_corners, st);
+}

@@ -31,6 +31,23 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {  // 4 bf16 = one 8-by
                      __uint_as_float(r.y & 0xffff0000u));
 }
 
+__device__ __forceinline__ void up2_source(int d, int n_in, int n_out, bool align, int& i0, int& i1, float& l0,
+                                           float& l1) {
+  // ATen/native/UpSample.h area_pixel_compute_source_index + the index / lambda arithmetic of upsample_bilinear2d
+  float src;
+  if (align) {
+    const float scale = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+    src = scale * (float)d;
+  } else {
+    src = 0.5f * ((float)d + 0.5f) - 0.5f;  // scale_factor = 2 given: scale = 1 / 2
+    src = src < 0.f ? 0.f : src;
+  }
+  i0 = min((int)src, n_in - 1);
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
 namespace fwd_win {
 constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24;
 // CCH = channels staged per chunk.  These kernels are latency-bound chains (flow -> taps -> box -> window -> taps),
@@ -259,23 +276,6 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const TS* __restrict__ sr
 //   launch folds into its epilogue: the normalised maps are never written (the moment pass and the apply pass of
 //   featnorm.hip and ATen's interpolate + mul launches disappear).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void up2_source(int d, int n_in, int n_out, bool align, int& i0, int& i1, float& l0,
-                                           float& l1) {
-  // ATen/native/UpSample.h area_pixel_compute_source_index + the index / lambda arithmetic of upsample_bilinear2d
-  float src;
-  if (align) {
-    const float scale = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
-    src = scale * (float)d;
-  } else {
-    src = 0.5f * ((float)d + 0.5f) - 0.5f;  // scale_factor = 2 given: scale = 1 / 2
-    src = src < 0.f ? 0.f : src;
-  }
-  i0 = min((int)src, n_in - 1);
-  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
-  l1 = src - (float)i0;
-  l0 = 1.f - l1;
-}
-
 template <bool UP>
 __global__ __launch_bounds__(256) void level_warp_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ src,
                                                              const float* __restrict__ flow, float* __restrict__ flow_up,
@@ -476,12 +476,17 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
 }
 }  // namespace flow_grad
 
+// add1 / add2 (nullable): further gradients of the same flow tensor that are added on the way out (sample b at
+// add1 + b * add1_bs resp. add2 + b * 2 * H * W) -- the level backward folds the gradient the decoder's concatenation
+// and the residual sum return for the upsampled flow in here instead of two ATen add passes.
 template <int CCH, typename TS = float>
 __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restrict__ gout,
                                                             const TS* __restrict__ src,
                                                             const float* __restrict__ flow, float* __restrict__ gflow,
                                                             int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
-                                                            int pad, int align, int norm) {
+                                                            int pad, int align, int norm,
+                                                            const float* __restrict__ add1 = nullptr, long add1_bs = 0,
+                                                            const float* __restrict__ add2 = nullptr) {
   using namespace fwd_win;
   __shared__ __attribute__((aligned(16))) float win[CCH * HMAX * 72];
   __shared__ int red[4][4];
@@ -527,14 +532,64 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
   }
   if (inside) {
     float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
+    float rx = gix * t.dx, ry = giy * t.dy;
+    if (blockIdx.y == 0) {
+      const long o = (long)y * W + x;
+      if (add1) rx += add1[(long)b * add1_bs + o], ry += add1[(long)b * add1_bs + os + o];
+      if (add2) rx += add2[(long)b * 2 * os + o], ry += add2[(long)b * 2 * os + os + o];
+    }
     if (gridDim.y == 1) {
-      gf[0] = gix * t.dx;
-      gf[os] = giy * t.dy;
+      gf[0] = rx;
+      gf[os] = ry;
     } else {  // channel-split launch: partial sums meet in the pre-zeroed gflow
-      atomicAdd(gf, gix * t.dx);
-      atomicAdd(gf + os, giy * t.dy);
+      atomicAdd(gf, rx);
+      atomicAdd(gf + os, ry);
     }
   }
+}
+
+// Adjoint of the x2 bilinear flow upsample of the level forward (up2_source), times the factor 2 of
+// interpolate(flow * 2): one thread per coarse cell gathers the fine pixels that read it -- rows 2i-2 .. 2i+3 cover
+// either align flag -- in a fixed order (ATen's backward scatters with atomics; this one is reproducible).
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ gfine, float* __restrict__ gcoarse,
+                                                      int planes, int H, int W, int up_align) {
+  const int Hc = H / 2, Wc = W / 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)planes * Hc * Wc) return;
+  const int j = (int)(idx % Wc), i = (int)((idx / Wc) % Hc);
+  const long pl = idx / ((long)Wc * Hc);
+  const float* g = gfine + pl * H * W;
+  float wy[6], wx[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int a0, a1;
+    float l0, l1;
+    const int y = 2 * i - 2 + k;
+    wy[k] = 0.f;
+    if (y >= 0 && y < H) {
+      up2_source(y, Hc, H, up_align != 0, a0, a1, l0, l1);
+      wy[k] = (a0 == i ? l0 : 0.f) + (a1 == i ? l1 : 0.f);
+    }
+    const int x = 2 * j - 2 + k;
+    wx[k] = 0.f;
+    if (x >= 0 && x < W) {
+      up2_source(x, Wc, W, up_align != 0, a0, a1, l0, l1);
+      wx[k] = (a0 == j ? l0 : 0.f) + (a1 == j ? l1 : 0.f);
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 6; ++ky) {
+    const int y = min(max(2 * i - 2 + ky, 0), H - 1);
+    float row = 0.f;
+#pragma unroll
+    for (int kx = 0; kx < 6; ++kx) {
+      const int x = min(max(2 * j - 2 + kx, 0), W - 1);
+      row = fmaf(wx[kx], g[(long)y * W + x], row);
+    }
+    acc = fmaf(wy[ky], row, acc);
+  }
+  gcoarse[idx] = 2.f * acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -914,6 +969,22 @@ extern "C" int arflow_warp_fwd(const float* src, const float* flow, float* out, 
   return af_launch_status();
 }
 
+int af_level_warp_fwd_launch(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                             int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
+                             double* acc, int B, int C, int H, int W, int pad_mode, int align_corners, int norm_mode,
+                             hipStream_t st) {
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  const dim3 grid(af_grid_for_tiles(tiles), channel_split(tiles, C));
+  if (flow_is_coarse)
+    hipLaunchKernelGGL(level_warp_fwd_kernel<true>, grid, dim3(256), 0, st, x1, x2, flow, flow_up, flow_up2,
+                       flow_up2_bstride, x2w, acc, B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode,
+                       up_align_corners);
+  else
+    hipLaunchKernelGGL(level_warp_fwd_kernel<false>, grid, dim3(256), 0, st, x1, x2, flow, nullptr, nullptr,
+                       0L, x2w, acc, B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode, 0);
+  return af_launch_status();
+}
+
 // ---- level entry points: see level_warp_fwd_kernel -------------------------------------------
 extern "C" int arflow_level_acc_rows(int B, int C, int H, int W, int has_flow) {
   if (!(B > 0 && C > 0 && H > 0 && W > 0)) return ARFLOW_ESHAPE;
@@ -944,32 +1015,16 @@ extern "C" int arflow_level_warp_fwd(const float* x1, const float* x2, const flo
   } else {
     AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
   }
-  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
-  const dim3 grid(af_grid_for_tiles(tiles), channel_split(tiles, C));
-  if (flow_is_coarse)
-    hipLaunchKernelGGL(level_warp_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, flow, flow_up, flow_up2,
-                       flow_up2_bstride, x2w, acc, B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode,
-                       up_align_corners);
-  else
-    hipLaunchKernelGGL(level_warp_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, flow, nullptr, nullptr,
-                       0L, x2w, acc, B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode, 0);
-  return af_launch_status();
+  return af_level_warp_fwd_launch(x1, x2, flow, flow_bstride, flow_is_coarse, up_align_corners, flow_up, flow_up2,
+                                  flow_up2_bstride, x2w, acc, B, C, H, W, pad_mode, align_corners, norm_mode,
+                                  (hipStream_t)stream);
 }
 
-extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float* flow, float* gsrc,
-                               float* gflow, int B, int C, int Hs, int Ws, int H, int W, long flow_bstride,
-                               int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {
-  af_clear_stale_error();
-  AF_REQUIRE_PTR(gout);
-  AF_REQUIRE_PTR(src);
-  AF_REQUIRE_PTR(flow);
-  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, ARFLOW_ESHAPE);
-  AF_REQUIRE(B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
-  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
-  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
-  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+// internal launcher (also used by the level entry points, level.hip); add1 / add2: see warp_bwd_flow_kernel
+int af_warp_bwd_launch(const float* gout, const float* src, const float* flow, float* gsrc, float* gflow, int B, int C,
+                       int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode, int align_corners, int norm_mode,
+                       const float* add1, long add1_bs, const float* add2, hipStream_t st) {
   if (!gsrc && !gflow) return ARFLOW_OK;
-  hipStream_t st = (hipStream_t)stream;
   if (gsrc) {
     hipError_t e = hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * C * Hs * Ws, st);
     if (e != hipSuccess) return af_hip_status(e);
@@ -987,12 +1042,35 @@ extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float*
     }
     if (C <= 3)
       hipLaunchKernelGGL(warp_bwd_flow_kernel<3>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
-                         gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+                         gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode, add1, add1_bs, add2);
     else
       hipLaunchKernelGGL(warp_bwd_flow_kernel<2>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
-                         gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+                         gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode, add1, add1_bs, add2);
   }
   return af_launch_status();
+}
+
+int af_up2_bwd_launch(const float* gfine, float* gcoarse, int planes, int H, int W, int up_align, hipStream_t st) {
+  const long n = (long)planes * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(up2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gfine, gcoarse, planes, H, W,
+                     up_align);
+  return af_launch_status();
+}
+
+extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float* flow, float* gsrc,
+                               float* gflow, int B, int C, int Hs, int Ws, int H, int W, long flow_bstride,
+                               int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gout);
+  AF_REQUIRE_PTR(src);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+  return af_warp_bwd_launch(gout, src, flow, gsrc, gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners,
+                            norm_mode, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int arflow_splat_map(const float* flow, float* out, int B, int H, int W, long flow_bstride,

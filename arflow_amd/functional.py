@@ -448,30 +448,26 @@ class LevelFunction(torch.autograd.Function):
         acc = torch.empty(4 * B * rows, device=x1.device, dtype=torch.float64)
         stats = torch.empty(B, 4, device=x1.device, dtype=torch.float32)
         sign = torch.empty(B, 3, H, W, device=x1.device, dtype=torch.int32) if cfg.slope != 1.0 else None
-        flow_full = x2w = None
+        flow_full = x2w = x1n = None
+        fbs, fslot, fup = 0, None, None
+        if has_flow:
+            flow, fbs = _flow_view(flow)
+            x2w = torch.empty_like(x2)
+            if cfg.flow_is_coarse:
+                flow_full = fup = torch.empty(B, 2, H, W, device=x1.device, dtype=torch.float32)
+                fslot = buf[:, offs['flow']:].data_ptr() if 'flow' in offs else None
+            else:
+                flow_full = flow
+        if 'x1n' in offs:
+            x1n_ptr, x1n_bs = buf[:, offs['x1n']:].data_ptr(), bs
+        else:
+            x1n = torch.empty_like(x1)
+            x1n_ptr, x1n_bs = x1n.data_ptr(), C * H * W
         with torch.cuda.device_of(x1):
-            if has_flow:
-                flow, fbs = _flow_view(flow)
-                x2w = torch.empty_like(x2)
-                if cfg.flow_is_coarse:
-                    flow_full = torch.empty(B, 2, H, W, device=x1.device, dtype=torch.float32)
-                    fslot = buf[:, offs['flow']:].data_ptr() if 'flow' in offs else None
-                    _call('arflow_level_warp_fwd', _p(x1), _p(x2), _p(flow), fbs, 1, int(cfg.up_align), _p(flow_full), fslot,
-                          bs, _p(x2w), _p(acc), B, C, H, W, cfg.pad, cfg.align, cfg.norm, _stream(), key=(B, C, H, W, 1))
-                else:
-                    flow_full = flow
-                    _call('arflow_level_warp_fwd', _p(x1), _p(x2), _p(flow), fbs, 0, 0, None, None, 0, _p(x2w), _p(acc),
-                          B, C, H, W, cfg.pad, cfg.align, cfg.norm, _stream(), key=(B, C, H, W, 0))
-            else:
-                _call('arflow_level_moments', _p(x1), _p(x2), _p(acc), B, C * H * W, _stream(), key=(B, C * H * W))
-            if 'x1n' in offs:
-                x1n, x1n_ptr, x1n_bs = None, buf[:, offs['x1n']:].data_ptr(), bs
-            else:
-                x1n = torch.empty_like(x1)
-                x1n_ptr, x1n_bs = x1n.data_ptr(), C * H * W
-            _call('arflow_level_corr_fwd', _p(x1), _p(x2w if has_flow else x2), _p(acc), rows, cfg.mode,
-                  buf[:, offs['vol']:].data_ptr(), bs, x1n_ptr, x1n_bs, _p(sign), _p(stats), B, C, H, W, cfg.d, cfg.slope,
-                  _stream(), key=(B, C, H, W, cfg.d, 3 if sign is not None else 0))
+            _call('arflow_level_fwd', _p(x1), _p(x2), _p(flow), fbs, int(cfg.flow_is_coarse and has_flow), int(cfg.up_align),
+                  _p(fup), fslot, bs, _p(x2w), cfg.mode, buf[:, offs['vol']:].data_ptr(), bs, x1n_ptr, x1n_bs, _p(sign),
+                  _p(stats), _p(acc), B, C, H, W, cfg.d, cfg.slope, cfg.pad, cfg.align, cfg.norm, _stream(),
+                  key=(B, C, H, W, cfg.d, 3 if sign is not None else 0, int(has_flow) + int(has_flow and cfg.flow_is_coarse)))
         for item in cfg.layout:
             if not isinstance(item, str):
                 buf[:, offs[item]:offs[item] + int(members[item].shape[1])].copy_(members[item])
@@ -494,37 +490,25 @@ class LevelFunction(torch.autograd.Function):
             x1n_ptr, x1n_bs = x1n_holder[:, offs['x1n']:].data_ptr(), bs
         else:
             x1n_ptr, x1n_bs = x1n_holder.data_ptr(), C * H * W
-        g1, g2 = torch.empty_like(x1), torch.empty_like(x1)
-        d1, d2 = torch.empty_like(x1), torch.empty_like(x1)
-        acc = _featnorm_acc(B, x1.device)
-        gx2 = gflow_in = None
+        d1, gx2 = torch.empty_like(x1), torch.empty_like(x1)
+        ws = torch.empty(_lib.load().arflow_level_bwd_ws_bytes(B, C, H, W), device=x1.device, dtype=torch.uint8)
+        gflow_in = fl = gslot = None
+        fbs = 0
+        coarse = ctx.has_flow and cfg.flow_is_coarse
+        if ctx.has_flow:
+            fl, fbs = _flow_view(flow_full)
+            gflow_in = torch.empty(B, 2, H // 2, W // 2, device=x1.device, dtype=torch.float32) if coarse else \
+                torch.empty(B, 2, H, W, device=x1.device, dtype=torch.float32)
+            if 'flow' in offs:
+                gslot = gbuf[:, offs['flow']:].data_ptr()
+            if gflow_ext is not None:
+                gflow_ext = gflow_ext.contiguous()
+        gdir = gbuf[:, offs['x1n']:].data_ptr() if 'x1n' in offs else None
         with torch.cuda.device_of(x1):
-            _call('arflow_level_corr_bwd', gbuf[:, offs['vol']:].data_ptr(), bs, _p(sign), x1n_ptr, x1n_bs,
-                  _p(x2w if ctx.has_flow else x2), _p(stats), _p(g1), _p(g2), B, C, H, W, cfg.d, cfg.slope, _stream(),
-                  key=(B, C, H, W, cfg.d, 3 if sign is not None else 0))
-            if 'x1n' in offs:
-                g1 = g1 + gbuf[:, offs['x1n']:offs['x1n'] + C]
-            n = C * H * W
-            _call('arflow_featnorm_bwd', _p(g1), _p(g2), _p(x1), _p(x2w if ctx.has_flow else x2), _p(stats), _p(acc), _p(d1),
-                  _p(d2), B, n, cfg.mode, _stream(), key=(B, n))
-            if ctx.has_flow:
-                gx2 = torch.empty_like(x2)
-                gfl = torch.empty(B, 2, H, W, device=x1.device, dtype=torch.float32)
-                fl, fbs = _flow_view(flow_full)
-                _call('arflow_warp_bwd', _p(d2), _p(x2), _p(fl), _p(gx2), _p(gfl), B, C, H, W, H, W, fbs, cfg.pad, cfg.align,
-                      cfg.norm, _stream(), key=(B, C, H, W, True))
-                if cfg.flow_is_coarse:
-                    if 'flow' in offs:
-                        gfl = gfl + gbuf[:, offs['flow']:offs['flow'] + 2]
-                    if gflow_ext is not None:
-                        gfl = gfl + gflow_ext
-                    # interpolate(2 f) backward: the adjoint of ATen's bilinear upsample, times 2
-                    gflow_in = torch.ops.aten.upsample_bilinear2d_backward(gfl, [H, W], [B, 2, H // 2, W // 2], cfg.up_align,
-                                                                           2.0, 2.0) * 2.0
-                else:
-                    gflow_in = gfl
-            else:
-                gx2 = d2
+            _call('arflow_level_bwd', gbuf[:, offs['vol']:].data_ptr(), bs, _p(sign), x1n_ptr, x1n_bs, gdir, bs, _p(x1),
+                  _p(x2), _p(x2w), _p(fl), fbs, gslot, bs, _p(gflow_ext), _p(stats), cfg.mode, _p(d1), _p(gx2), _p(gflow_in),
+                  int(coarse), int(cfg.up_align), _p(ws), B, C, H, W, cfg.d, cfg.slope, cfg.pad, cfg.align, cfg.norm,
+                  _stream(), key=(B, C, H, W, cfg.d, 3 if sign is not None else 0, int(ctx.has_flow) + int(coarse)))
         gm, k = [], 0
         for item in cfg.layout:
             if not isinstance(item, str):

@@ -88,6 +88,28 @@ def algorithmic_bytes(name, shape):
     if name == 'arflow_warp_bwd_bf16':
         B, C, H, W, with_src = shape
         return B * H * W * (4 * C + 2 * C + 16 + (4 * C if with_src else 0))
+    if name == 'arflow_level_fwd':  # raw x1, x2 in; x2w (with a flow), volume + sign words, normalised x1 out; flow in/out
+        B, C, H, W, d, act, fk = shape
+        flow = {0: 0.0, 1: 2.0, 2: 0.5 + 4.0}[fk]
+        return int(4 * B * H * W * (2 * C + (C if fk else 0) + (2 * d + 1) ** 2 + act + C + flow))
+    if name == 'arflow_level_bwd':  # gvol + signs, x1n, its direct gradient, x1, x2 (+ x2w, flow) in; gx1, gx2 (+ gflow) out
+        B, C, H, W, d, act, fk = shape
+        flow = {0: 0.0, 1: 2.0 + 2.0, 2: 2.0 + 4.0 + 0.5}[fk]
+        return int(4 * B * H * W * ((2 * d + 1) ** 2 + act + (7 if fk else 6) * C + flow))
+    if name == 'arflow_level_warp_fwd':  # x1 (moments), x2 in; x2w out; coarse flow in, upsampled flow out twice
+        B, C, H, W, up = shape
+        return 4 * B * H * W * (3 * C + 2) + (4 * B * H * W * 2 + 2 * B * H * W if up else 0)
+    if name == 'arflow_level_moments':
+        B, n = shape
+        return 4 * B * n * 2
+    if name == 'arflow_level_corr_fwd':  # raw x1, x2w in; volume (+ sign words) and the normalised first map out
+        B, C, H, W, d = shape[:5]
+        act = shape[5] if len(shape) > 5 else 0
+        return 4 * B * H * W * (3 * C + (2 * d + 1) ** 2 + act)
+    if name == 'arflow_level_corr_bwd':
+        B, C, H, W, d = shape[:5]
+        act = int(shape[5]) if len(shape) > 5 else 0
+        return 4 * B * H * W * ((2 * d + 1) ** 2 + act + 4 * C)
     if name == 'arflow_featnorm_fwd':
         B, n = shape
         return 4 * B * n * 4  # two tensors in, two out (the second read of the inputs is not compulsory)
@@ -169,15 +191,18 @@ def valu_slots(name, shape):
     if name == 'arflow_photo_bwd':
         B, C, H, W = shape  # window coefficients (as forward) + 9 windows x 3 fma per pixel
         return B * C * H * W * (5 + 45 + 45 + 2 * T + 27)
-    if name in ('arflow_corr_fwd', 'arflow_corr_fwd_strided'):
+    if name in ('arflow_corr_fwd', 'arflow_corr_fwd_strided', 'arflow_level_corr_fwd', 'arflow_level_fwd'):
         B, C, H, W, d = shape[:5]
         return B * H * W * (2 * d + 1) ** 2 * C
-    if name in ('arflow_corr_bwd', 'arflow_corr_bwd_strided'):
+    if name in ('arflow_corr_bwd', 'arflow_corr_bwd_strided', 'arflow_level_corr_bwd', 'arflow_level_bwd'):
         B, C, H, W, d = shape[:5]
         return B * H * W * (2 * d + 1) ** 2 * C * 2
     if name == 'arflow_warp_fwd':
         B, C, H, W = shape  # coordinates + taps ~60, 4 fma per channel
         return B * H * W * (60 + 4 * C)
+    if name == 'arflow_level_warp_fwd':
+        B, C, H, W = shape[:4]  # + the moments: 4 per channel
+        return B * H * W * (80 + 8 * C)
     if name == 'arflow_warp_bwd':
         B, C, H, W, with_src = shape  # flow gradient: 8 per channel; source gradient: 4 per channel
         return B * H * W * (70 + (12 if with_src else 8) * C)
@@ -509,7 +534,7 @@ def main():
                                                                            'GBps': algorithmic_bytes(k[0], k[1]) / (v[0] / v[1] * 1e-3) / 1e9,
                                                                            'bound': roofs[k]['bound'], 'frac_of_roof': roofs[k]['frac'],
                                                                            'valu_busy_pmc': roofs[k]['valu_busy_pmc']}
-                                            for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])[:14]}}
+                                            for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(args.workload, H, W)

@@ -145,6 +145,29 @@ int arflow_featnorm_bwd(const float* g1, const float* g2, const float* x1, const
  * or flow_up2 (batch stride flow_up2_bstride) receive it) or [B,2,H,W]; flow_bstride = floats between samples.
  * out / x1n: volume and normalised first map with batch strides (slots of a concatenated buffer); stats: [B,4]
  * (m1, m2, mu, sigma).  Needs the fast-path shapes (arflow_corr_strided_supported). */
+/* The level as ONE call per direction (the entry points the host models use; the stage entry points further down
+ * remain for callers that keep their own intermediate buffers):
+ *   arflow_level_fwd  = [arflow_level_warp_fwd | arflow_level_moments] + arflow_level_corr_fwd, back to back;
+ *   arflow_level_bwd  = arflow_level_corr_bwd + the normalisation's backward (gx1n_direct, the gradient the decoder's
+ *     concatenation returns for x1n, is added on load) + the warp's backward (gflow_a [batch stride] and gflow_b
+ *     [contiguous], further gradients of the upsampled flow, are added on the way out) + the adjoint of the x2 flow
+ *     upsample.  gflow: [B,2,H/2,W/2] with flow_is_coarse, else [B,2,H,W]; flow_full: the fine flow the forward
+ *     warped with (flow_up of the forward, or the caller's fine flow; NULL at the level without a warp -- then x2w,
+ *     gflow*, gflow are ignored and gx2 is the normalisation's second gradient).
+ *   workspace: arflow_level_bwd_ws_bytes(B, C, H, W) bytes of scratch, 256-byte aligned; acc as for the stages. */
+int arflow_level_supported(int C, int W, int max_disp);
+long arflow_level_bwd_ws_bytes(int B, int C, int H, int W);
+int arflow_level_fwd(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                     int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w, int norm_mode,
+                     float* out, long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits, float* stats,
+                     double* acc, int B, int C, int H, int W, int max_disp, float negative_slope, int pad_mode,
+                     int align_corners, int coord_norm, arflow_stream_t stream);
+int arflow_level_bwd(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n, long x1n_bstride,
+                     const float* gx1n_direct, long gx1n_direct_bstride, const float* x1, const float* x2, const float* x2w,
+                     const float* flow_full, long flow_bstride, const float* gflow_a, long gflow_a_bstride,
+                     const float* gflow_b, const float* stats, int norm_mode, float* gx1, float* gx2, float* gflow,
+                     int flow_is_coarse, int up_align_corners, void* workspace, int B, int C, int H, int W, int max_disp,
+                     float negative_slope, int pad_mode, int align_corners, int coord_norm, arflow_stream_t stream);
 int arflow_level_acc_rows(int B, int C, int H, int W, int has_flow);
 int arflow_level_moments(const float* x1, const float* x2, double* acc, int B, long n, arflow_stream_t stream);
 int arflow_level_warp_fwd(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--sets', type=int, default=8)
     ap.add_argument('--iters', type=int, default=40)
+    ap.add_argument('--filter', default='')
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device('cuda')
@@ -63,6 +64,23 @@ def main():
         ('arflow_featnorm_fwd', (B, n), lambda d: lib.arflow_featnorm_fwd(p(d['x1']), p(d['x2']), p(d['g1']), p(d['g2']), p(d['acc']), p(d['st']), B, n, 0, s)),
         ('arflow_featnorm_bwd', (B, n), lambda d: lib.arflow_featnorm_bwd(p(d['go'][:, :C]), p(d['out'][:, :C]), p(d['x1']), p(d['x2']), p(d['st']), p(d['acc']), p(d['g1']), p(d['g2']), B, n, 0, s)),
     ]
+    # fused level launches on the same cold buffer sets
+    rows = lib.arflow_level_acc_rows(B, C, h, w, 1)
+    for d in sets:
+        d['fc'] = 1.5 * torch.randn(B, 2, h // 2, w // 2, device=dev, generator=g)
+        d['lacc'] = torch.empty(4 * B * rows, device=dev, dtype=torch.float64)
+        d['fu'] = torch.empty(B, 2, h, w, device=dev)
+        lib.arflow_level_warp_fwd(p(d['x1']), p(d['x2']), p(d['fc']), 2 * (h // 2) * (w // 2), 1, 1, p(d['fu']), None, 0, p(d['g2']),
+                                  p(d['lacc']), B, C, h, w, 0, 1, 0, s)
+        lib.arflow_level_corr_fwd(p(d['x1']), p(d['g2']), p(d['lacc']), rows, 0, p(d['out']), 81 * h * w, p(d['g1']), C * h * w,
+                                  p(d['sign']), p(d['st']), B, C, h, w, 4, 0.1, s)
+    ops += [
+        ('arflow_level_warp_fwd', (B, C, h, w, 1), lambda d: lib.arflow_level_warp_fwd(p(d['x1']), p(d['x2']), p(d['fc']), 2 * (h // 2) * (w // 2), 1, 1, p(d['fu']), None, 0, p(d['g2']), p(d['lacc']), B, C, h, w, 0, 1, 0, s)),
+        ('arflow_level_corr_fwd', (B, C, h, w, 4, 3), lambda d: lib.arflow_level_corr_fwd(p(d['x1']), p(d['x2']), p(d['lacc']), rows, 0, p(d['out']), 81 * h * w, p(d['g1']), C * h * w, p(d['sign']), p(d['st']), B, C, h, w, 4, 0.1, s)),
+        ('arflow_level_corr_bwd', (B, C, h, w, 4, 3), lambda d: lib.arflow_level_corr_bwd(p(d['go']), 81 * h * w, p(d['sign']), p(d['x1']), C * h * w, p(d['x2']), p(d['st']), p(d['g1']), p(d['g2']), B, C, h, w, 4, 0.1, s)),
+    ]
+    if args.filter:
+        ops = [o for o in ops if any(f in o[0] for f in args.filter.split('|'))]
     for name, shape, fn in ops:
         us = timeit(fn)
         nb = algorithmic_bytes(name, shape)
