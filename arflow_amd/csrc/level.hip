@@ -61,6 +61,14 @@ extern "C" int arflow_level_fwd(const float* x1, const float* x2, const float* f
   const int rows = arflow_level_acc_rows(B, C, H, W, flow != nullptr);
   if (flow) {
     AF_REQUIRE_PTR(x2w);
+    AF_REQUIRE(!flow_is_coarse || (H % 2 == 0 && W % 2 == 0), ARFLOW_ESHAPE);
+  }
+  if (af_level_small_ok(C, H, W) && max_disp == 4)  // coarse level: one workgroup per sample, ONE launch
+    return af_level_small_fwd_launch(x1, x2, flow, flow_bstride, flow_is_coarse, up_align_corners, flow_up, flow_up2,
+                                     flow_up2_bstride, x2w, norm_mode, out, out_bstride, x1n, x1n_bstride,
+                                     negative_slope == 1.0f ? nullptr : sign_bits, stats, B, C, H, W, negative_slope,
+                                     pad_mode, align_corners, coord_norm, st);
+  if (flow) {
     AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
     AF_REQUIRE(coord_norm == ARFLOW_NORM_ARFLOW || coord_norm == ARFLOW_NORM_UFLOW, ARFLOW_EPARAM);
     if (flow_is_coarse) {

@@ -23,3 +23,11 @@ int af_level_corr_fwd_launch(const float* x1, const float* x2w, const double* ac
 int af_level_corr_bwd_launch(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
                              long x1n_bstride, const float* x2w, const float* stats, float* gx1n, float* gx2n, int B, int C,
                              int H, int W, float negative_slope, hipStream_t st);
+
+// coarse levels (H * W <= 1024): one workgroup per sample, one launch per direction (level_small.hip)
+bool af_level_small_ok(int C, int H, int W);
+int af_level_small_fwd_launch(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                              int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
+                              int norm_mode, float* out, long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits,
+                              float* stats, int B, int C, int H, int W, float negative_slope, int pad_mode, int align_corners,
+                              int coord_norm, hipStream_t st);

@@ -55,6 +55,24 @@ __device__ __forceinline__ TapPlan plan_taps(const Taps& t, int Hs, int Ws) {
   return p;
 }
 
+// Source rows / weights of output index d of the x2 bilinear upsample n_in -> n_out = 2 n_in:
+// ATen/native/UpSample.h area_pixel_compute_source_index + the index / lambda arithmetic of upsample_bilinear2d.
+__device__ __forceinline__ void up2_source(int d, int n_in, int n_out, bool align, int& i0, int& i1, float& l0,
+                                           float& l1) {
+  float src;
+  if (align) {
+    const float scale = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+    src = scale * (float)d;
+  } else {
+    src = 0.5f * ((float)d + 0.5f) - 0.5f;  // scale_factor = 2 given: scale = 1 / 2
+    src = src < 0.f ? 0.f : src;
+  }
+  i0 = min((int)src, n_in - 1);
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
 __device__ __forceinline__ Taps no_taps() {
   Taps t;
   t.vx0 = t.vx1 = t.vy0 = t.vy1 = false;

@@ -31,23 +31,6 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {  // 4 bf16 = one 8-by
                      __uint_as_float(r.y & 0xffff0000u));
 }
 
-__device__ __forceinline__ void up2_source(int d, int n_in, int n_out, bool align, int& i0, int& i1, float& l0,
-                                           float& l1) {
-  // ATen/native/UpSample.h area_pixel_compute_source_index + the index / lambda arithmetic of upsample_bilinear2d
-  float src;
-  if (align) {
-    const float scale = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
-    src = scale * (float)d;
-  } else {
-    src = 0.5f * ((float)d + 0.5f) - 0.5f;  // scale_factor = 2 given: scale = 1 / 2
-    src = src < 0.f ? 0.f : src;
-  }
-  i0 = min((int)src, n_in - 1);
-  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
-  l1 = src - (float)i0;
-  l0 = 1.f - l1;
-}
-
 namespace fwd_win {
 constexpr int TX = 32, TY = 8, NT = 256, HMAX = 24;
 // CCH = channels staged per chunk.  These kernels are latency-bound chains (flow -> taps -> box -> window -> taps),
