@@ -345,7 +345,13 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
                                                     float* __restrict__ gx2, int B, int C, int H, int W,
                                                     float inv_c, int mode_base, int nmodes,
                                                     long gbs /* batch stride of gout */, long fbs /* of fout */,
-                                                    long x1bs /* batch stride of x1 */, const float* __restrict__ stats) {
+                                                    long x1bs /* batch stride of x1 */, const float* __restrict__ stats,
+                                                    float* __restrict__ zero_c, float* __restrict__ zero_f,
+                                                    float* __restrict__ zero_fc) {
+  // zero_c [B,C,H,W], zero_f [B,2,H,W], zero_fc [B,2,H/2,W/2] (level backward, each nullable): accumulation targets of the
+  // warp backward that follows, zero-filled HERE -- mode-1 workgroups clear their tile of zero_c next to the gradient
+  // they store, split-0 mode-0 workgroups their tile of the two flow-gradient buffers -- instead of by fill launches
+  // (two of the seven launches a coarse level's backward consisted of)
   constexpr int BUF = SRC_FLOATS;
   // Cross-wave sum of the per-wave partials.  Channel c of a chunk is OWNED by wave c % 3: the other two waves
   // publish their 4-pixel partials for it in LDS, the owner keeps its own in registers and, one iteration later
@@ -524,6 +530,21 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
 
   float own[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // this wave's partials of the channels it owns
   const bool lane_in = gy < H && gx < W;
+  if constexpr (NORM) {
+    if (mode == 0 && split == 0 && wave == 0 && lane_in) {
+      if (zero_f) {
+        float* z = zero_f + (long)b * 2 * cs + (long)gy * W + gx;
+        *reinterpret_cast<float4*>(z) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(z + cs) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (zero_fc && (gy & 1) == 0) {  // the 2 coarse cells under the lane's 4 pixels, both planes
+        const int Hc = H / 2, Wc = W / 2;
+        float* z = zero_fc + (long)b * 2 * Hc * Wc + (long)(gy >> 1) * Wc + (gx >> 1);
+        *reinterpret_cast<float2*>(z) = make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(z + (long)Hc * Wc) = make_float2(0.f, 0.f);
+      }
+    }
+  }
   // add the three waves' partials of chunk `chunk` (in wave order, as before: bit-identical results) and store
   auto reduce_store = [&](int chunk, int par) {
     const float* pp = part + par * PART1;
@@ -541,9 +562,13 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
         const float w2 = wave == 2 ? o[p] : (wave == 0 ? s1[p] : s0[p]);
         r[p] = ((w0 + w1) + w2) * inv_c;
       }
-      if (lane_in)
-        *reinterpret_cast<float4*>(dstb + (long)((split + chunk * nsplit) * CC + c) * cs + (long)gy * W + gx) =
-            make_float4(r[0], r[1], r[2], r[3]);
+      if (lane_in) {
+        const long o = (long)((split + chunk * nsplit) * CC + c) * cs + (long)gy * W + gx;
+        *reinterpret_cast<float4*>(dstb + o) = make_float4(r[0], r[1], r[2], r[3]);
+        if constexpr (NORM) {
+          if (mode == 1 && zero_c) *reinterpret_cast<float4*>(zero_c + (long)b * C * cs + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
     }
   };
   int par = 0;
@@ -621,7 +646,8 @@ inline int launch_fwd(const float* x1, const float* x2, float* out, unsigned* si
 inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign_bits, float slope, const float* x1,
                       const float* x2,
                       float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st, long gbs = 0, long fbs = 0,
-                      long x1bs = 0, const float* stats = nullptr) {
+                      long x1bs = 0, const float* stats = nullptr, float* zero_c = nullptr, float* zero_f = nullptr,
+                      float* zero_fc = nullptr) {
   if (gbs == 0) gbs = (long)N * N * H * W;
   if (fbs == 0) fbs = (long)N * N * H * W;
   if (x1bs == 0) x1bs = (long)C * H * W;
@@ -636,7 +662,7 @@ inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign
   const int mb = gx1 ? 0 : 1;
 #define CORR_V2_BWD(NB, ACT, NN)                                                                                      \
   hipLaunchKernelGGL((bwd_kernel<NB, ACT, NN>), grid, dim3(NT), 0, st, gout, fout, sign_bits, slope, x1, x2, gx1, gx2, \
-                     B, C, H, W, inv_c, mb, nmodes, gbs, fbs, x1bs, stats)
+                     B, C, H, W, inv_c, mb, nmodes, gbs, fbs, x1bs, stats, zero_c, zero_f, zero_fc)
   if (stats) {  // level kernels: always with the sign words of the fused LeakyReLU (ACT 2) or without activation (0)
     if (act == 1) return ARFLOW_EPARAM;
     if (tiles >= 768) {

@@ -378,6 +378,15 @@ int af_featnorm_bwd_apply_launch(const float* g1, const float* g1b, long g1b_bs,
   return af_launch_status();
 }
 
+// sum pass alone (any n): rows of (sum g, sum g (x - mu)) in `acc`; returns the rows per sample through *nrows
+int af_featnorm_bwd_sums_launch(const float* g1, const float* g1b, long g1b_bs, const float* g2, const float* x1,
+                                const float* x2, const float* stats, double* acc, int* nrows, int B, long n, hipStream_t st) {
+  const unsigned rows = blocks_per_sample(B, n, NT * VPT);
+  *nrows = (int)rows;
+  hipLaunchKernelGGL(bwd_sum_kernel, dim3(rows, B), dim3(NT), 0, st, g1, g2, x1, x2, stats, acc, n, g1b, g1b_bs);
+  return af_launch_status();
+}
+
 int af_featnorm_moments_launch(const float* x1, const float* x2, double* acc, int B, long n, hipStream_t st) {
   const unsigned rows = blocks_per_sample(B, n, NT * VPT);
   hipLaunchKernelGGL(moment_kernel, dim3(rows, B), dim3(NT), 0, st, x1, x2, acc, n);

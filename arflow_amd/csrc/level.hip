@@ -17,15 +17,14 @@
 namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct BwdWs {
-  size_t g1, g2, d2, gfl, acc, total;
+  size_t g1, g2, gfl, acc, total;
 };
 inline BwdWs bwd_layout(int B, int C, int H, int W) {
   BwdWs w;
   const size_t n = align256(sizeof(float) * (size_t)B * C * H * W);
   w.g1 = 0;
   w.g2 = n;
-  w.d2 = 2 * n;
-  w.gfl = 3 * n;
+  w.gfl = 2 * n;
   w.acc = w.gfl + align256(sizeof(float) * (size_t)B * 2 * H * W);
   w.total = w.acc + align256(sizeof(double) * (size_t)ARFLOW_FEATNORM_ACC_DOUBLES(B));
   return w;
@@ -119,7 +118,6 @@ extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsi
   char* base = (char*)workspace;
   float* g1 = (float*)(base + ws.g1);
   float* g2 = (float*)(base + ws.g2);
-  float* d2 = (float*)(base + ws.d2);
   float* gfl = (float*)(base + ws.gfl);
   double* acc = (double*)(base + ws.acc);
   const bool has_flow = flow_full != nullptr;
@@ -133,16 +131,24 @@ extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsi
     AF_REQUIRE(gflow_a == nullptr || gflow_a_bstride >= 2L * H * W, ARFLOW_ESHAPE);
   }
   const float* second = has_flow ? x2w : x2;
+  // (the upsample's adjoint through float atomics inside the warp launch was tried for the coarse levels: the channel-split
+  // workgroups of a tile all add into the same few coarse cells -- 24x40 backward 48 -> 77 us; the gather kernel stays)
+  const bool up_atomic = false;
   int rc = af_level_corr_bwd_launch(gout, gout_bstride, sign_bits, x1n, x1n_bstride, second, stats, g1, g2, B, C, H, W,
-                                    negative_slope, st);
+                                    negative_slope, st, has_flow ? gx2 : nullptr,
+                                    has_flow ? (flow_is_coarse ? gfl : gflow) : nullptr, up_atomic ? gflow : nullptr);
   if (rc != ARFLOW_OK) return rc;
-  // the normalisation's backward (the concatenation's gradient of x1n added on load); without a warp its second
-  // output IS d/d x2
-  rc = af_featnorm_bwd_launch(g1, gx1n_direct, gx1n_direct_bstride, g2, x1, second, stats, acc, gx1, has_flow ? d2 : gx2, B,
-                              (long)C * H * W, norm_mode, st);
-  if (rc != ARFLOW_OK || !has_flow) return rc;
-  rc = af_warp_bwd_launch(d2, x2, flow_full, gx2, flow_is_coarse ? gfl : gflow, B, C, H, W, H, W, flow_bstride, pad_mode,
-                          align_corners, coord_norm, gflow_a, gflow_a_bstride, gflow_b, st);
-  if (rc != ARFLOW_OK || !flow_is_coarse) return rc;
+  if (!has_flow)  // the normalisation's backward (the concatenation's gradient of x1n added on load): its outputs ARE the results
+    return af_featnorm_bwd_launch(g1, gx1n_direct, gx1n_direct_bstride, g2, x1, x2, stats, acc, gx1, gx2, B, (long)C * H * W,
+                                  norm_mode, st);
+  // with a warp: only the two sums of the normalisation's backward; its apply pass is folded into the loads of the
+  // warp's two gradient kernels (the gradient of the raw warped map is never written)
+  int nrows = 0;
+  rc = af_featnorm_bwd_sums_launch(g1, gx1n_direct, gx1n_direct_bstride, g2, x1, x2w, stats, acc, &nrows, B, (long)C * H * W, st);
+  if (rc != ARFLOW_OK) return rc;
+  rc = af_level_warp_bwd_launch(g2, x2, x2w, flow_full, flow_bstride, gx2, flow_is_coarse ? gfl : gflow, B, C, H, W, pad_mode,
+                                align_corners, coord_norm, acc, nrows, stats, norm_mode, g1, gx1n_direct, gx1n_direct_bstride,
+                                x1, gx1, gflow_a, gflow_a_bstride, gflow_b, up_atomic ? gflow : nullptr, up_align_corners, st);
+  if (rc != ARFLOW_OK || !flow_is_coarse || up_atomic) return rc;
   return af_up2_bwd_launch(gfl, gflow, B * 2, H, W, up_align_corners, st);
 }

@@ -416,19 +416,54 @@ __device__ __forceinline__ TileBox tile_bbox(const Taps& t, int (*red)[4], int* 
 // ------------------------------------------------------------------------------------------------
 namespace flow_grad {
 using fwd_win::HMAX;
-template <int WQ, int CCH, typename TS>
+// NB (level backward): `gop` holds the gradient of the NORMALISED warped map; the normalisation's backward
+//     d = r g - r G / N - r^3 Q (x - c) / (N - 1)         (featnorm.hip, bwd_apply_kernel)
+// is applied on load -- x, the warped value, is the bilinear sum of the four taps this kernel reads anyway -- so the
+// gradient of the raw warped map is never written; the same pass applies it to the first map's gradient
+// (g1p + gdp, with x1p) and stores d/d x1 (d1p), all at the thread's pixel.
+struct NormBwd {
+  float rf, cg, cq, c1, c2;
+};
+__device__ __forceinline__ NormBwd norm_bwd_coeffs(const double* rows, int nrows, const float* st, long n, int mode) {
+  double gq[2];
+  featnorm::sum_rows<2>(rows, nrows, gq);
+  const double r = 1.0 / (double)st[3], dn = (double)n;
+  NormBwd nb;
+  nb.rf = (float)r;
+  nb.cg = (float)(r * gq[0] / (2.0 * dn));
+  nb.cq = (float)(mode == ARFLOW_FEATNORM_JOINT ? r * r * r * gq[1] / (2.0 * dn - 1.0) : r * r * r * gq[1] / (2.0 * (dn - 1.0)));
+  nb.c1 = mode == ARFLOW_FEATNORM_JOINT ? st[2] : st[0];
+  nb.c2 = mode == ARFLOW_FEATNORM_JOINT ? st[2] : st[1];
+  return nb;
+}
+__device__ __forceinline__ float norm_bwd_apply(const NormBwd& nb, float g, float x, float c) {
+  return fmaf(nb.rf, g, -nb.cg) - nb.cq * (x - c);
+}
+
+template <int WQ, int CCH, typename TS, bool NB = false>
 __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restrict__ sp,
                                     const float* __restrict__ gop, const TapPlan& p, const Taps& t, bool inside, int C,
                                     int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
-                                    float& gix, float& giy) {
+                                    float& gix, float& giy, const NormBwd* nb = nullptr,
+                                    const float* __restrict__ g1p = nullptr, const float* __restrict__ gdp = nullptr,
+                                    const float* __restrict__ x1p = nullptr, float* __restrict__ d1p = nullptr) {
   constexpr int WP = 4 * WQ;
   using fwd_win::WindowPlan;
   const WindowPlan<WQ> pl = fwd_win::window_plan<WQ>(Ws, ax0, by0, bh);
   float4 v[CCH][WindowPlan<WQ>::ITER];
   float gn[CCH];  // the next chunk's output gradients travel with its window
+  float an[CCH], xn[CCH];  // NB: first map's gradient (both parts added) and value
   auto fetch_g = [&](int c0) {
 #pragma unroll
-    for (int c = 0; c < CCH; ++c) gn[c] = (inside && c0 + c < C) ? gop[(long)(c0 + c) * os] : 0.f;
+    for (int c = 0; c < CCH; ++c) {
+      const bool ok = inside && c0 + c < C;
+      gn[c] = ok ? gop[(long)(c0 + c) * os] : 0.f;
+      if (NB) {
+        an[c] = ok ? g1p[(long)(c0 + c) * os] : 0.f;
+        if (gdp) an[c] += ok ? gdp[(long)(c0 + c) * os] : 0.f;
+        xn[c] = ok ? x1p[(long)(c0 + c) * os] : 0.f;
+      }
+    }
   };
   const int step = gridDim.y * CCH;
   int c0 = blockIdx.y * CCH;
@@ -440,6 +475,11 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
     float g[CCH];
 #pragma unroll
     for (int c = 0; c < CCH; ++c) g[c] = gn[c];
+    if (NB) {
+#pragma unroll
+      for (int c = 0; c < CCH; ++c)
+        if (inside && c0 + c < C) d1p[(long)(c0 + c) * os] = norm_bwd_apply(*nb, an[c], xn[c], nb->c1);
+    }
     fwd_win::window_store<WQ, CCH>(win, v, pl, c0, C);
     if (c0 + step < C) {
       fetch_g(c0 + step);
@@ -451,8 +491,13 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
       const float* w = win + c * HMAX * WP;
       const float nw = p.ok[0] ? w[l0] : 0.f, ne = p.ok[1] ? w[l1] : 0.f;
       const float sw = p.ok[2] ? w[l2] : 0.f, se = p.ok[3] ? w[l3] : 0.f;
-      gix = fmaf(g[c], (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
-      giy = fmaf(g[c], (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
+      float gc = g[c];
+      if (NB) {
+        const float xw = fmaf(se, p.w[3], fmaf(sw, p.w[2], fmaf(ne, p.w[1], nw * p.w[0])));
+        gc = norm_bwd_apply(*nb, gc, xw, nb->c2);
+      }
+      gix = fmaf(gc, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
+      giy = fmaf(gc, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
     }
     __syncthreads();
   }
@@ -531,6 +576,113 @@ __global__ __launch_bounds__(256) void warp_bwd_flow_kernel(const float* __restr
   }
 }
 
+// Level backward, the warp's flow gradient with the normalisation's backward folded in (flow_grad::run<.., NB>): reads
+// the gradients of the NORMALISED maps (g2n for the warped one, g1n + gdir for the first one), writes d/d x1 and the
+// flow gradient (+ add1 + add2).  Coefficients from the partial rows of featnorm's bwd_sum_kernel.
+struct LevelBwdArgs {
+  const double* rows;
+  int nrows, mode;
+  const float* stats;
+  const float* g1n;
+  const float* gdir;  // nullable
+  long gdir_bs;
+  const float* x1;
+  float* d1;
+  float* gcoarse;  // non-null: the flow gradient goes straight through the adjoint of the x2 upsample into this PRE-ZEROED
+  int up_align;    // [B,2,H/2,W/2] tensor with float atomics (coarse levels: one launch less than up2_bwd_kernel)
+};
+__global__ __launch_bounds__(256) void level_warp_bwd_flow_kernel(const float* __restrict__ g2n, const float* __restrict__ src,
+                                                                  const float* __restrict__ flow, float* __restrict__ gflow,
+                                                                  int nimg, int C, int H, int W, long fbs, int pad, int align,
+                                                                  int norm, const float* __restrict__ add1, long add1_bs,
+                                                                  const float* __restrict__ add2, LevelBwdArgs la) {
+  using namespace fwd_win;
+  constexpr int CCH = 2;
+  __shared__ __attribute__((aligned(16))) float win[CCH * HMAX * 72];
+  __shared__ int red[4][4];
+  __shared__ int box[4];
+  int btx, bty, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b)) return;
+  const int x = btx * TX + (int)(threadIdx.x & 31), y = bty * TY + (int)(threadIdx.x >> 5);
+  const bool inside = x < W && y < H;
+  const int Hs = H, Ws = W;
+  const int ss = Hs * Ws, os = H * W;
+  const flow_grad::NormBwd nb = flow_grad::norm_bwd_coeffs(la.rows + 4L * la.nrows * b, la.nrows, la.stats + 4 * b,
+                                                            (long)C * os, la.mode);
+  Taps t = no_taps();
+  if (inside) {
+    const float* fb = flow + (long)b * fbs + (long)y * W + x;
+    t = make_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
+  }
+  const TapPlan p = plan_taps(t, Hs, Ws);
+  const TileBox bb = tile_bbox(t, red, box);
+  const int bh = bb.y1 - bb.y0 + 1, ax0 = bb.x0 & ~3, aw = bb.x1 - ax0 + 1;
+  const bool empty = bb.x1 < bb.x0;
+  const float* sp = src + (long)b * C * ss;
+  const long po = (long)b * C * os + (long)y * W + x;
+  const float* gop = g2n + po;
+  const float* g1p = la.g1n + po;
+  const float* gdp = la.gdir ? la.gdir + (long)b * la.gdir_bs + (long)y * W + x : nullptr;
+  const float* x1p = la.x1 + po;
+  float* d1p = la.d1 + po;
+  float gix = 0.f, giy = 0.f;
+  if (!empty && (Ws & 3) == 0 && bh <= HMAX && aw <= 72) {
+    const int xa = min(max(t.x0, 0), Ws - 1) - ax0, xb = min(max(t.x0 + 1, 0), Ws - 1) - ax0;
+    const int ya = min(max(t.y0, 0), Hs - 1) - bb.y0, yb = min(max(t.y0 + 1, 0), Hs - 1) - bb.y0;
+    const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
+    const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
+    if (aw <= 48)
+      flow_grad::run<12, CCH, float, true>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa,
+                                           cya * 48 + cxb, cyb * 48 + cxa, cyb * 48 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p);
+    else
+      flow_grad::run<18, CCH, float, true>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa,
+                                           cya * 72 + cxb, cyb * 72 + cxa, cyb * 72 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p);
+  } else if (inside) {
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {  // no tap inside the source, or a window too large: direct gathers
+      const float gsum = g1p[(long)c * os] + (gdp ? gdp[(long)c * os] : 0.f);
+      d1p[(long)c * os] = flow_grad::norm_bwd_apply(nb, gsum, x1p[(long)c * os], nb.c1);
+      if (empty) continue;
+      const float* s = sp + (long)c * ss;
+      float a0 = s[p.o[0]], a1 = s[p.o[1]], a2 = s[p.o[2]], a3 = s[p.o[3]];
+      asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      const float nw = p.ok[0] ? a0 : 0.f, ne = p.ok[1] ? a1 : 0.f, sw = p.ok[2] ? a2 : 0.f, se = p.ok[3] ? a3 : 0.f;
+      const float xw = fmaf(se, p.w[3], fmaf(sw, p.w[2], fmaf(ne, p.w[1], nw * p.w[0])));
+      const float g = flow_grad::norm_bwd_apply(nb, gop[(long)c * os], xw, nb.c2);
+      gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
+      giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
+    }
+  }
+  if (inside) {
+    float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
+    float rx = gix * t.dx, ry = giy * t.dy;
+    if (blockIdx.y == 0) {
+      const long o = (long)y * W + x;
+      if (add1) rx += add1[(long)b * add1_bs + o], ry += add1[(long)b * add1_bs + os + o];
+      if (add2) rx += add2[(long)b * 2 * os + o], ry += add2[(long)b * 2 * os + os + o];
+    }
+    if (la.gcoarse) {
+      const int Hc = H / 2, Wc = W / 2;
+      int xa, xb, ya, yb;
+      float wx0, wx1, wy0, wy1;
+      up2_source(x, Wc, W, la.up_align != 0, xa, xb, wx0, wx1);
+      up2_source(y, Hc, H, la.up_align != 0, ya, yb, wy0, wy1);
+      float* gc = la.gcoarse + (long)b * 2 * Hc * Wc;
+      const long cs = (long)Hc * Wc;
+      rx *= 2.f, ry *= 2.f;  // interpolate(2 f)
+      atomicAdd(gc + ya * Wc + xa, wy0 * wx0 * rx), atomicAdd(gc + ya * Wc + xb, wy0 * wx1 * rx);
+      atomicAdd(gc + yb * Wc + xa, wy1 * wx0 * rx), atomicAdd(gc + yb * Wc + xb, wy1 * wx1 * rx);
+      atomicAdd(gc + cs + ya * Wc + xa, wy0 * wx0 * ry), atomicAdd(gc + cs + ya * Wc + xb, wy0 * wx1 * ry);
+      atomicAdd(gc + cs + yb * Wc + xa, wy1 * wx0 * ry), atomicAdd(gc + cs + yb * Wc + xb, wy1 * wx1 * ry);
+    } else if (gridDim.y == 1) {
+      gf[0] = rx;
+      gf[os] = ry;
+    } else {
+      atomicAdd(gf, rx);
+      atomicAdd(gf + os, ry);
+    }
+  }
+}
+
 // Adjoint of the x2 bilinear flow upsample of the level forward (up2_source), times the factor 2 of
 // interpolate(flow * 2): one thread per coarse cell gathers the fine pixels that read it -- rows 2i-2 .. 2i+3 cover
 // either align flag -- in a fixed order (ATen's backward scatters with atomics; this one is reproducible).
@@ -594,10 +746,16 @@ constexpr int TX = 32, TY = 8, NT = TX * TY;
 constexpr int WMAX = 128, HMAX = 64, NCELL = WMAX * HMAX, CCH = 4;
 static_assert(CCH == 4, "gt holds one float4 per pixel");
 
+// NB (level backward): gout is the gradient of the NORMALISED warped map; the normalisation's backward is applied while
+// the gradients are staged (flow_grad::norm_bwd_apply with x = the saved warped map `x2w`), see level_warp_bwd_flow_kernel.
+template <bool NB = false>
 __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restrict__ gout,
                                                           const float* __restrict__ flow, float* __restrict__ gsrc,
                                                           int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
-                                                          int pad, int align, int norm) {
+                                                          int pad, int align, int norm,
+                                                          const float* __restrict__ x2w = nullptr,
+                                                          const double* __restrict__ rows = nullptr, int nrows = 0,
+                                                          const float* __restrict__ stats = nullptr, int mode = 0) {
   // cell c lives at halfword cell_ptr[c + (c >> 5)]: the scan walks a lane-private run of consecutive cells,
   // and the +1-per-32 skew keeps 64 lanes with a stride that is a multiple of 32 off a common bank.
   // 16-bit cells (a workgroup has at most 4 * 256 = 1024 list entries) halve the array: 17 KB instead of
@@ -636,11 +794,15 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
   const long ss = (long)Hs * Ws, os = (long)H * W;
   float* gp = gsrc + (long)b * C * ss;
   const float* gop = gout + (long)b * C * os + (long)y * W + x;
+  const float* xwp = NB ? x2w + (long)b * C * os + (long)y * W + x : nullptr;
+  flow_grad::NormBwd nb;
+  if (NB) nb = flow_grad::norm_bwd_coeffs(rows + 4L * nrows * b, nrows, stats + 4 * b, (long)C * os, mode);
 
   if (!priv) {
     if (inside)
       for (int c = blockIdx.y; c < C; c += gridDim.y) {
-        const float g = gop[c * os];
+        float g = gop[c * os];
+        if (NB) g = flow_grad::norm_bwd_apply(nb, g, xwp[c * os], nb.c2);
         float* d = gp + c * ss + o00;
         if (ok[0]) atomicAdd(d, g * wgt[0]);
         if (ok[1]) atomicAdd(d + 1, g * wgt[1]);
@@ -721,8 +883,17 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
   //    entry brings its 4 channels), gather per non-empty cell, one global atomic per cell and channel
   int buf = 0;
   auto fetch = [&](int c0, float (&v)[CCH]) {
+    float xv[CCH];
 #pragma unroll
-    for (int c = 0; c < CCH; ++c) v[c] = (c0 + c < C && inside) ? gop[(c0 + c) * os] : 0.f;
+    for (int c = 0; c < CCH; ++c) {
+      const bool ok = c0 + c < C && inside;
+      v[c] = ok ? gop[(c0 + c) * os] : 0.f;
+      if (NB) xv[c] = ok ? xwp[(c0 + c) * os] : 0.f;
+    }
+    if (NB) {
+#pragma unroll
+      for (int c = 0; c < CCH; ++c) v[c] = (c0 + c < C && inside) ? flow_grad::norm_bwd_apply(nb, v[c], xv[c], nb.c2) : 0.f;
+    }
   };
   float nv[CCH];  // the next chunk's gradients travel while the current chunk is gathered
   fetch(blockIdx.y * CCH, nv);
@@ -1015,7 +1186,7 @@ int af_warp_bwd_launch(const float* gout, const float* src, const float* flow, f
   const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
   const unsigned nsplit = channel_split(tiles, C);
   if (gsrc)
-    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
+    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel<false>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
                        flow, gsrc, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
   if (gsrc && gflow) AF_LAUNCH_CHECK();
   if (gflow) {
@@ -1030,6 +1201,27 @@ int af_warp_bwd_launch(const float* gout, const float* src, const float* flow, f
       hipLaunchKernelGGL(warp_bwd_flow_kernel<2>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout, src, flow,
                          gflow, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode, add1, add1_bs, add2);
   }
+  return af_launch_status();
+}
+
+// level backward, warp part: the normalisation's backward folded into both warp-gradient kernels (no apply pass, the
+// gradient of the raw warped map is never written).  rows: partial (sum g, sum g (x - mu)) rows of featnorm's sum pass.
+int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w, const float* flow, long flow_bstride,
+                             float* gx2, float* gflow, int B, int C, int H, int W, int pad_mode, int align_corners,
+                             int norm_mode, const double* rows, int nrows, const float* stats, int featnorm_mode,
+                             const float* g1n, const float* gdir, long gdir_bs, const float* x1, float* gx1,
+                             const float* add1, long add1_bs, const float* add2, float* gcoarse, int up_align,
+                             hipStream_t st) {
+  // gx2, gflow (and gcoarse) arrive ZERO-FILLED (by the correlation backward launch in front of this one)
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  const unsigned nsplit = channel_split(tiles, C);
+  const dim3 grid(af_grid_for_tiles(tiles), nsplit);
+  hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel<true>, grid, dim3(256), 0, st, g2n, flow, gx2, B, C, H, W, H, W,
+                     flow_bstride, pad_mode, align_corners, norm_mode, x2w, rows, nrows, stats, featnorm_mode);
+  AF_LAUNCH_CHECK();
+  LevelBwdArgs la{rows, nrows, featnorm_mode, stats, g1n, gdir, gdir_bs, x1, gx1, gcoarse, up_align};
+  hipLaunchKernelGGL(level_warp_bwd_flow_kernel, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
+                     pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
   return af_launch_status();
 }
 
@@ -1144,7 +1336,7 @@ extern "C" int arflow_warp_bwd_bf16(const float* gout, const unsigned short* src
   const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
   const unsigned nsplit = channel_split(tiles, C);
   if (gsrc)
-    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
+    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel<false>, dim3(af_grid_for_tiles(tiles), nsplit), dim3(256), 0, st, gout,
                        flow, gsrc, B, C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
   if (gsrc && gflow) AF_LAUNCH_CHECK();
   if (gflow) {
