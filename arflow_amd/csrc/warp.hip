@@ -591,11 +591,11 @@ struct LevelBwdArgs {
   float* gcoarse;  // non-null: the flow gradient goes straight through the adjoint of the x2 upsample into this PRE-ZEROED
   int up_align;    // [B,2,H/2,W/2] tensor with float atomics (coarse levels: one launch less than up2_bwd_kernel)
 };
-__global__ __launch_bounds__(256) void level_warp_bwd_flow_kernel(const float* __restrict__ g2n, const float* __restrict__ src,
-                                                                  const float* __restrict__ flow, float* __restrict__ gflow,
-                                                                  int nimg, int C, int H, int W, long fbs, int pad, int align,
-                                                                  int norm, const float* __restrict__ add1, long add1_bs,
-                                                                  const float* __restrict__ add2, LevelBwdArgs la) {
+__device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict__ g2n, const float* __restrict__ src,
+                                                         const float* __restrict__ flow, float* __restrict__ gflow,
+                                                         int nimg, int C, int H, int W, long fbs, int pad, int align,
+                                                         int norm, const float* __restrict__ add1, long add1_bs,
+                                                         const float* __restrict__ add2, const LevelBwdArgs& la) {
   using namespace fwd_win;
   constexpr int CCH = 2;
   __shared__ __attribute__((aligned(16))) float win[CCH * HMAX * 72];
@@ -683,6 +683,14 @@ __global__ __launch_bounds__(256) void level_warp_bwd_flow_kernel(const float* _
   }
 }
 
+__global__ __launch_bounds__(256) void level_warp_bwd_flow_kernel(const float* __restrict__ g2n, const float* __restrict__ src,
+                                                                  const float* __restrict__ flow, float* __restrict__ gflow,
+                                                                  int nimg, int C, int H, int W, long fbs, int pad, int align,
+                                                                  int norm, const float* __restrict__ add1, long add1_bs,
+                                                                  const float* __restrict__ add2, LevelBwdArgs la) {
+  level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la);
+}
+
 // Adjoint of the x2 bilinear flow upsample of the level forward (up2_source), times the factor 2 of
 // interpolate(flow * 2): one thread per coarse cell gathers the fine pixels that read it -- rows 2i-2 .. 2i+3 cover
 // either align flag -- in a fixed order (ATen's backward scatters with atomics; this one is reproducible).
@@ -748,14 +756,14 @@ static_assert(CCH == 4, "gt holds one float4 per pixel");
 
 // NB (level backward): gout is the gradient of the NORMALISED warped map; the normalisation's backward is applied while
 // the gradients are staged (flow_grad::norm_bwd_apply with x = the saved warped map `x2w`), see level_warp_bwd_flow_kernel.
-template <bool NB = false>
-__global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restrict__ gout,
-                                                          const float* __restrict__ flow, float* __restrict__ gsrc,
-                                                          int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
-                                                          int pad, int align, int norm,
-                                                          const float* __restrict__ x2w = nullptr,
-                                                          const double* __restrict__ rows = nullptr, int nrows = 0,
-                                                          const float* __restrict__ stats = nullptr, int mode = 0) {
+template <bool NB>
+__device__ __forceinline__ void warp_bwd_src_body(const float* __restrict__ gout,
+                                                  const float* __restrict__ flow, float* __restrict__ gsrc,
+                                                  int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
+                                                  int pad, int align, int norm,
+                                                  const float* __restrict__ x2w,
+                                                  const double* __restrict__ rows, int nrows,
+                                                  const float* __restrict__ stats, int mode) {
   // cell c lives at halfword cell_ptr[c + (c >> 5)]: the scan walks a lane-private run of consecutive cells,
   // and the +1-per-32 skew keeps 64 lanes with a stride that is a multiple of 32 off a common bank.
   // 16-bit cells (a workgroup has at most 4 * 256 = 1024 list entries) halve the array: 17 KB instead of
@@ -937,7 +945,34 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
     // reads before this buffer is overwritten two chunks later
   }
 }
+template <bool NB = false>
+__global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restrict__ gout,
+                                                          const float* __restrict__ flow, float* __restrict__ gsrc,
+                                                          int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
+                                                          int pad, int align, int norm,
+                                                          const float* __restrict__ x2w = nullptr,
+                                                          const double* __restrict__ rows = nullptr, int nrows = 0,
+                                                          const float* __restrict__ stats = nullptr, int mode = 0) {
+  warp_bwd_src_body<NB>(gout, flow, gsrc, nimg, C, Hs, Ws, H, W, fbs, pad, align, norm, x2w, rows, nrows, stats, mode);
+}
 }  // namespace lds_scatter
+
+// Coarse / middle pyramid levels: the two independent gradient kernels of the warp as ONE launch (blockIdx.z picks the
+// role), so that they overlap instead of paying two launch latencies back to back on a few hundred tiles.  (The fine
+// level keeps them apart: together they need 51 KB of LDS, 3 workgroups per CU instead of 4 and 8.)
+__global__ __launch_bounds__(256) void level_warp_bwd_both_kernel(const float* __restrict__ g2n, const float* __restrict__ src,
+                                                                  const float* __restrict__ x2w,
+                                                                  const float* __restrict__ flow, float* __restrict__ gsrc,
+                                                                  float* __restrict__ gflow, int nimg, int C, int H, int W,
+                                                                  long fbs, int pad, int align, int norm,
+                                                                  const float* __restrict__ add1, long add1_bs,
+                                                                  const float* __restrict__ add2, LevelBwdArgs la) {
+  if (blockIdx.z == 0)
+    lds_scatter::warp_bwd_src_body<true>(g2n, flow, gsrc, nimg, C, H, W, H, W, fbs, pad, align, norm, x2w, la.rows, la.nrows,
+                                         la.stats, la.mode);
+  else
+    level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la);
+}
 
 // Forward splat of the 4 bilinear weights of every pixel's target position (compute_range_map /
 // get_corresponding_map).  One workgroup = an 8 x 32 tile of source pixels; their targets fall into a
@@ -1216,10 +1251,15 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
   const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
   const unsigned nsplit = channel_split(tiles, C);
   const dim3 grid(af_grid_for_tiles(tiles), nsplit);
+  LevelBwdArgs la{rows, nrows, featnorm_mode, stats, g1n, gdir, gdir_bs, x1, gx1, gcoarse, up_align};
+  if (tiles * nsplit <= 2048) {  // coarse / middle levels: both roles in one launch
+    hipLaunchKernelGGL(level_warp_bwd_both_kernel, dim3(grid.x, grid.y, 2), dim3(256), 0, st, g2n, x2, x2w, flow, gx2, gflow,
+                       B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
+    return af_launch_status();
+  }
   hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel<true>, grid, dim3(256), 0, st, g2n, flow, gx2, B, C, H, W, H, W,
                      flow_bstride, pad_mode, align_corners, norm_mode, x2w, rows, nrows, stats, featnorm_mode);
   AF_LAUNCH_CHECK();
-  LevelBwdArgs la{rows, nrows, featnorm_mode, stats, g1n, gdir, gdir_bs, x1, gx1, gcoarse, up_align};
   hipLaunchKernelGGL(level_warp_bwd_flow_kernel, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
                      pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
   return af_launch_status();
