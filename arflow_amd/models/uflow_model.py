@@ -117,19 +117,31 @@ class PWCFlow(nn.Module):
         context = flow = flow_up = context_up = None
         flows = []
         k = 0
-        for level in range(self._num_levels - 1, 0, -1):
+        top = self._num_levels - 1
+        for level in range(top, 0, -1):
             features1, features2 = feature_pyramid1[level], feature_pyramid2[level]
-            if flow_up is None:
-                warped2 = features2
+            fused = self._normalize_before_cost_volume and AF.level_supported(features1, None if level == top else flow, True)
+            if fused:
+                # the whole level in front of the flow layers as one call: x2 flow upsample
+                # (uflow_utils.upsample: align_corners=False), resample, normalisation, cost volume + LeakyReLU
+                if level == top:
+                    cfg = AF.LevelCfg(['vol', 0], 'avg', self._leaky_relu_alpha, 4)
+                    x_in = AF.level(features1, features2, None, cfg, features1)
+                else:
+                    cfg = AF.LevelCfg([0, 'flow', 'vol', 1], 'avg', self._leaky_relu_alpha, 4, True, False, 'zeros', True,
+                                      AF.NORM_UFLOW)
+                    x_in, flow_up = AF.level(features1, features2, flow, cfg, context_up, features1)
             else:
-                warped2 = uflow_utils.resample_flow(features2, flow_up)  # resample(f2, flow_to_warp(flow_up))
-            f1n, w2n = normalize_features([features1, warped2], normalize=self._normalize_before_cost_volume,
-                                          center=self._normalize_before_cost_volume,
-                                          moments_across_channels=True, moments_across_images=True)
-            # cost volume + fused LeakyReLU, written straight into its slot of the decoder's concatenated input
-            before = () if flow_up is None else (context_up, flow_up)
-            x_in = cost_volume_concat(f1n, w2n, before, (features1,), max_displacement=4,
-                                      negative_slope=self._leaky_relu_alpha)
+                if level != top:
+                    flow_up = uflow_utils.upsample(flow, is_flow=True)
+                warped2 = features2 if level == top else uflow_utils.resample_flow(features2, flow_up)
+                f1n, w2n = normalize_features([features1, warped2], normalize=self._normalize_before_cost_volume,
+                                              center=self._normalize_before_cost_volume,
+                                              moments_across_channels=True, moments_across_images=True)
+                # cost volume + fused LeakyReLU, written straight into its slot of the decoder's concatenated input
+                before = () if level == top else (context_up, flow_up)
+                x_in = cost_volume_concat(f1n, w2n, before, (features1,), max_displacement=4,
+                                          negative_slope=self._leaky_relu_alpha)
             layers = self._flow_layers[level]
             x_out = None
             for layer in layers[:-1]:
@@ -141,9 +153,8 @@ class PWCFlow(nn.Module):
                 context = context * drops[k]
                 flow = flow * drops[k]
             k += 1
-            if flow_up is not None:
+            if level != top:
                 flow = flow + flow_up
-            flow_up = uflow_utils.upsample(flow, is_flow=True)
             context_up = self._context_up_layers[level](context)
             flows.insert(0, flow)
         refinement = torch.cat([context, flow], dim=1)

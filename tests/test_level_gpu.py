@@ -151,3 +151,38 @@ def test_level_mean_far_from_zero(AF, O):
     buf = AF.level(x1.cuda(), x2.cuda(), None, cfg, member.cuda())
     assert_close(buf[:, 81:81 + C], ref_buf[:, 81:81 + C], 2e-5, 1e-5, 'x1n at mean = 25 sigma')
     assert_close(buf[:, :81], ref_buf[:, :81], 2e-5, 1e-5, 'volume at mean = 25 sigma')
+
+
+@pytest.mark.parametrize('shape', [(4, 32, 16, 28), (2, 32, 32, 56)], ids=lambda s: 'x'.join(map(str, s)))
+def test_level_uflow_layout(AF, O, shape):
+    """The level as PWCFlow runs it (models/uflow_model.py:160-198): upsample(flow, is_flow=True) (align_corners=False),
+    resample(f2, flow_to_warp(flow_up)), 'avg' statistics, cat([context_up, flow_up, volume, features1]) -- the
+    normalised first map is NOT concatenated (kept on the side for the backward), the raw one is a member."""
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(H)
+    x1 = (smooth(torch.randn(B, C, H, W, generator=gen)) + 0.2).requires_grad_(True)
+    x2 = (smooth(torch.randn(B, C, H, W, generator=gen)) - 0.1).requires_grad_(True)
+    flow_c = smooth(1.2 * torch.randn(B, 2, H // 2, W // 2, generator=gen)).requires_grad_(True)
+    ctx = torch.randn(B, 6, H, W, generator=gen).requires_grad_(True)
+    flow = F.interpolate(flow_c, scale_factor=2, mode='bilinear', align_corners=False) * 2
+    x2w = O.resample(x2, O.flow_to_warp(flow))
+    y1, y2 = O.normalize_features_uflow([x1, x2w], normalize=True, center=True, moments_across_channels=True,
+                                        moments_across_images=True)
+    pre = O.correlation(y1, y2, 4)
+    ref = torch.cat([ctx, flow, F.leaky_relu(pre, 0.1), x1], 1)
+    gbuf = torch.randn(ref.shape, generator=gen)
+    gbuf[:, 8:8 + 81] *= (pre.detach().abs() > 1e-6).float()
+    gflow = torch.randn(B, 2, H, W, generator=gen)
+    refs = torch.autograd.grad((ref * gbuf).sum() + (flow * gflow).sum(), [x1, x2, flow_c, ctx])
+
+    a, b, fc, cx = [t.detach().cuda().requires_grad_(True) for t in (x1, x2, flow_c, ctx)]
+    cfg = AF.LevelCfg([0, 'flow', 'vol', 1], 'avg', 0.1, 4, True, False, 'zeros', True, AF.NORM_UFLOW)
+    buf, fu = AF.level(a, b, fc, cfg, cx, a)
+    fmax = float(flow.detach().abs().max())
+    assert_close(fu, flow, 4e-7 * max(fmax, 1.0), 0, 'flow_up')
+    assert_close(buf[:, 8:8 + 81], ref[:, 8:8 + 81], 2e-6 + 2e-5 * float(x2.detach().abs().max()), 1e-5, 'volume')
+    assert_close(buf[:, :6], ctx, 0, 0, 'context copy')
+    assert_close(buf[:, -C:], x1, 0, 0, 'features1 copy')
+    got = torch.autograd.grad((buf * gbuf.cuda()).sum() + (fu * gflow.cuda()).sum(), [a, b, fc, cx])
+    for n, g, r in zip(['d x1', 'd x2', 'd flow', 'd context'], got, refs):
+        assert_close(g, r, 2e-5 * float(r.abs().max()) + 1e-6, 1e-4, n)
