@@ -19,6 +19,7 @@ c_f = ctypes.c_float
 PROTOTYPES = {
     'arflow_abi_version': [],
     'arflow_take_stale_error': [],
+    'arflow_profile_marker': [c_i, c_fp],
     'arflow_sums_rows': [c_i, c_i, c_i],
     'arflow_corr_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_fp],
     'arflow_corr_sign_planes': [c_i, c_i, c_i],

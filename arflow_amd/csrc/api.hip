@@ -22,6 +22,14 @@ void af_record_stale_error(int code) {
 
 extern "C" int arflow_take_stale_error(void) { return g_stale_code.exchange(0); }
 
+// Profiling aid (tools/kbench.py): a one-wave no-op kernel whose NAME delimits the dispatches of consecutive C-ABI calls
+// in a rocprofv3 kernel / counter trace, so that counters can be summed per CALL (an entry point may launch several kernels).
+__global__ void af_marker_kernel(int tag) { (void)tag; }
+extern "C" int arflow_profile_marker(int tag, arflow_stream_t stream) {
+  hipLaunchKernelGGL(af_marker_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tag);
+  return af_launch_status();
+}
+
 extern "C" const char* arflow_strerror(int code) {
   switch (code) {
     case ARFLOW_OK: return "ok";

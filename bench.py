@@ -167,18 +167,21 @@ def algorithmic_bytes(name, shape):
     return 0
 
 
-# Measured VALU ceilings of one MI355X (tools/ubench/valu_rate.hip, profiles/r02_valu_rate.log): v_fma_f32 issues
-# 55.4 T lane-instructions/s chip-wide (2.84 cycles per wave-instruction per SIMD), v_rsq_f32 / v_rcp_f32 19.2 T/s.
-# A kernel's algorithmic VALU work is priced in "v_fma slots": 1 per plain fp32 op, TRANS_SLOTS per transcendental.
-VALU_PEAK_TSLOTS = 55.4
+# VALU roof.  SPEC: 157.3 TFLOPS fp32 vector (MI355X_MICROARCH.md, chip-level parameters) = 78.6 T v_fma lane-instructions/s
+# (2 flop per FMA; v_fma_f32 issues over 2 cycles on a SIMD-32) -- the `peak` of every VALU-bound roofline entry.
+# MEASURED: tools/ubench/valu_rate.hip (profiles/r02_valu_rate.log) sustains 55.4 T v_fma/s and 19.2 T v_rsq/s on the whole chip;
+# reported next to the spec figure as `peak_measured`.  A kernel's algorithmic VALU work is priced in "v_fma slots": 1 per
+# plain fp32 op, TRANS_SLOTS per transcendental (the measured v_fma : v_rsq rate ratio).
+VALU_PEAK_SPEC_TSLOTS = 78.6
+VALU_PEAK_MEASURED_TSLOTS = 55.4
 TRANS_SLOTS = 55.4 / 19.2
 
 
-def valu_slots(name, shape):
+def valu_slots(name, shape, trans_slots=None):
     """Algorithmic VALU work of one launch in v_fma-equivalent lane slots (arithmetic the algorithm needs, not the
     instructions the kernel happens to issue): the counterpart of algorithmic_bytes() for the kernels the PMC pass
     shows VALU-bound (profiles/r02_pmc_valu.json).  0 = not modelled (HBM side only)."""
-    T = TRANS_SLOTS
+    T = TRANS_SLOTS if trans_slots is None else trans_slots  # trans_slots=1: plain instruction count of the same op model
     if name in ('arflow_census_fwd', 'arflow_census_warp_fwd'):
         B, H, W = shape[:3]  # 49 neighbours x (2 sub, 2 fma, 2 rsq, mul, fma, mul, add, rcp, fma) per image pair
         return B * H * W * 49 * (10 + 3 * T)
@@ -270,50 +273,71 @@ def _pmc_table(fname):
     return json.load(open(path)) if os.path.exists(path) else None
 
 
+def _call_key(name, shape):
+    return '%s|%s' % (name, ','.join(str(v) for v in shape))
+
+
 def pmc_traffic(name, shape):
-    """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
-    in separate runs of tools/kbench.py on the same shapes, gfx950 correction applied by tools/make_traffic.py), or
-    None when that launch shape was not profiled."""
+    """(HBM bytes per call, source) from the PMC passes kept under profiles/: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    separate runs of tools/kbench.py on the same shapes (warm caches), gfx950 correction applied (2 x FETCH_SIZE).  Round-3
+    tables are keyed by C-ABI call (tools/pmc_calls.py: an entry point may launch several kernels), older ones by kernel
+    symbol (tools/make_traffic.py).  (None, None) when that launch shape was not profiled."""
+    t = _pmc_table('r03_pmc_traffic.json')
+    k = _call_key(name, shape)
+    if t and k in t:
+        return t[k]['hbm_bytes'], {'file': 'profiles/r03_pmc_traffic.json', 'commit': t.get('_meta', {}).get('commit'),
+                                   'cache_state': 'warm (tools/kbench.py re-runs each call on the same buffers)'}
     keys = kernel_keys(name, shape)
     for fname in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         table = _pmc_table(fname)
-        if table and keys and all(k in table for k in keys):
-            return sum(table[k]['hbm_bytes'] for k in keys)
-    return None
+        if table and keys and all(kk in table for kk in keys):
+            return sum(table[kk]['hbm_bytes'] for kk in keys), {'file': 'profiles/' + fname, 'commit': 'an earlier round (kernel since unchanged or retuned: see DESIGN.md)',
+                                                               'cache_state': 'warm'}
+    return None, None
 
 
 def pmc_valu_busy(name, shape):
-    """Share of the chip's SIMD time the launch's dominant kernel spent issuing VALU instructions (PMC pass
-    profiles/r02_pmc_valu.json, tools/pmc_valu.py), or None."""
+    """(share of the chip's SIMD time the call spent issuing VALU instructions, source file) from the PMC pass
+    profiles/r03_pmc_valu.json (per call) or r02_pmc_valu.json (per kernel), or (None, None)."""
+    t = _pmc_table('r03_pmc_valu.json')
+    k = _call_key(name, shape)
+    if t and k in t and t[k].get('valu_busy') is not None:
+        return t[k]['valu_busy'], 'profiles/r03_pmc_valu.json @ %s' % t.get('_meta', {}).get('commit')
     table = _pmc_table('r02_pmc_valu.json')
     keys = kernel_keys(name, shape)
-    vals = [table[k]['valu_busy'] for k in keys if table and k in table and table[k].get('valu_busy') is not None]
-    return max(vals) if vals else None
+    vals = [table[kk]['valu_busy'] for kk in keys if table and kk in table and table[kk].get('valu_busy') is not None]
+    return (max(vals), 'profiles/r02_pmc_valu.json') if vals else (None, None)
 
 
 def roof(name, shape, avg_ms):
-    """Which roof bounds this launch and how close it runs to it: HBM time = algorithmic bytes / 8 TB/s, VALU time =
-    algorithmic slots / measured v_fma ceiling; the larger one is the bound.  `valu_busy_pmc` (share of the chip's SIMD
-    time spent issuing VALU instructions, from the PMC pass) is reported next to it: a kernel can sit under the HBM roof
-    of its ALGORITHM and still be limited by the instructions its implementation issues.  Returns the `roofline` object."""
+    """Which roof bounds this launch and how close it runs to it, priced from the SPEC: HBM time = algorithmic bytes / 8 TB/s,
+    VALU time = algorithmic slots / 78.6 T v_fma/s (157.3 TFLOPS fp32 vector); the larger one is the bound and `frac` is
+    that time over the measured time.  `hbm_frac` is always there (rounds stay comparable), `peak_measured` / `frac_measured`
+    price the same work against the ceiling tools/ubench/valu_rate.hip sustains on this chip (55.4 T v_fma/s).  `traffic` and
+    `valu_busy_pmc` are PMC table look-ups (tools/kbench.py runs, warm caches), each tagged with its source file and the commit
+    it was taken at -- not counters of this run.  Returns the `roofline` object."""
     nbytes, slots = algorithmic_bytes(name, shape), valu_slots(name, shape)
     t = avg_ms * 1e-3
-    t_hbm, t_valu = nbytes / (HBM_PEAK_GBS * 1e9), slots / (VALU_PEAK_TSLOTS * 1e12)
-    busy = pmc_valu_busy(name, shape)
+    t_hbm, t_valu = nbytes / (HBM_PEAK_GBS * 1e9), slots / (VALU_PEAK_SPEC_TSLOTS * 1e12)
+    busy, busy_src = pmc_valu_busy(name, shape)
+    traffic, traffic_src = pmc_traffic(name, shape)
     hbm = {'achieved': nbytes / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': t_hbm / t}
     r = {'kernel': name, 'shape': list(shape), 'avg_us': 1e6 * t, 'algorithmic_bytes': nbytes,
-         'traffic': pmc_traffic(name, shape), 'valu_busy_pmc': busy}
+         'traffic': traffic, 'traffic_source': traffic_src, 'valu_busy_pmc': busy, 'valu_busy_source': busy_src,
+         'hbm_frac': t_hbm / t, 'floor_us': 1e6 * max(t_hbm, t_valu)}
     if slots and t_valu > t_hbm:
-        r.update({'bound': 'valu', 'achieved': slots / t / 1e12, 'peak': VALU_PEAK_TSLOTS, 'unit': 'T v_fma-slots/s',
-                  'frac': t_valu / t, 'algorithmic_valu_slots': slots, 'hbm': hbm})
+        r.update({'bound': 'valu', 'achieved': slots / t / 1e12, 'peak': VALU_PEAK_SPEC_TSLOTS, 'unit': 'T v_fma-slots/s',
+                  'frac': t_valu / t, 'peak_measured': VALU_PEAK_MEASURED_TSLOTS,
+                  'frac_measured': slots / (VALU_PEAK_MEASURED_TSLOTS * 1e12) / t, 'algorithmic_valu_slots': slots, 'hbm': hbm})
     else:
-        r.update({'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm['frac']})
+        r.update({'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm['frac'],
+                  'peak_measured': 6290.0, 'frac_measured': nbytes / 6.29e12 / t})
     return r
 
 
-def cpu_baseline(workload, height, width, budget_s=25.0):
-    """The oracle (CPU restatement, kind 'port') on this host's cores: same workload shape, bounded
-    sample (batch 1, a few steps).  Baseline only -- never the thing shipped."""
+def cpu_baseline(workload, height, width, batch, budget_s=25.0):
+    """The oracle (CPU restatement, kind 'port') on this host's cores: the SAME workload shape and batch as the GPU line,
+    bounded sample (one warm-up step, then timed steps until ~25 s are spent).  Baseline only -- never the thing shipped."""
     from oracle import losses as OL  # checker / baseline only
     from oracle.host_models import oracle_ops
     from arflow_amd.train_step import WORKLOADS, synthetic_pairs
@@ -327,7 +351,7 @@ def cpu_baseline(workload, height, width, budget_s=25.0):
     loss_cls = {'uflow': OL.UFlowLoss, 'unflow': OL.unFlowLoss, 'fullres': OL.FullResLoss, 'mv': OL.MvLoss}[lcfg['type']]
     loss = loss_cls(AttrDict(lcfg))
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    B = 1
+    B = int(batch)
     frames = mcfg.get('n_frames', 2)
     x = synthetic_pairs(B, height, width, frames=frames, device='cpu')
     # the GPU box gives one GPU a 16-core CPU share: more torch threads than that only oversubscribe
@@ -353,7 +377,7 @@ def cpu_baseline(workload, height, width, budget_s=25.0):
             if time.time() - t_start > budget_s and times:
                 break
     per_step = sum(times) / len(times)
-    return {'value': B / per_step, 'unit': 'image-pairs/s', 'cores': cores, 'kind': 'port',
+    return {'value': B / per_step, 'unit': 'image-pairs/s', 'cores': cores, 'kind': 'port', 'batch': B,
             'sample': 'oracle/ (pure-PyTorch CPU restatement) full step (fwd+bwd+Adam) of %s at batch %d, %dx%d, '
                       '%d timed step(s) after 1 warm-up, torch threads=%d' % (workload, B, height, width, len(times), cores)}
 
@@ -491,7 +515,9 @@ def main():
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'loss_finite': finite},
             # ranks that took part in the gradient all-reduce and the backend that carried it ('nccl' = RCCL)
-            'rccl_ranks': dist.get_world_size() if use_dist else 0,
+            # rccl_ranks counts ranks only when RCCL ('nccl') carried the all-reduce; a gloo rehearsal reports 0 there
+            'collective_ranks': dist.get_world_size() if use_dist else 0,
+            'rccl_ranks': dist.get_world_size() if (use_dist and backend == 'nccl') else 0,
             'collective_backend': backend if use_dist else None,
             'oversubscribed': bool(oversub),
             'global_loss_norm': os.environ.get('ARFLOW_GLOBAL_LOSS_NORM') == '1',
@@ -523,21 +549,26 @@ def main():
             hb_ms = sum(v[0] for _, v in hb) / len(sampled)
             hb_bytes = sum(algorithmic_bytes(k[0], k[1]) * v[1] for k, v in hb) / len(sampled)
             at_roof_ms = sum(roofs[k]['frac'] * v[0] for k, v in per.items()) / len(sampled)
+            # the time the path would take with every launch AT the spec roof that bounds it (HBM 8 TB/s or 78.6 T v_fma/s)
+            floor_ms = sum(roofs[k]['floor_us'] * 1e-3 * v[1] for k, v in per.items()) / len(sampled)
             line['hot_path'] = {'ms_per_step': hot_ms, 'algorithmic_GB_per_step': hot_bytes / 1e9,
                                 'GBps': hot_bytes / (hot_ms * 1e-3) / 1e9,
                                 'frac_of_hbm_peak': hot_bytes / (hot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 'hbm_bound_only': {'ms_per_step': hb_ms, 'algorithmic_GB_per_step': hb_bytes / 1e9,
                                                    'frac_of_hbm_peak': (hb_bytes / (hb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hb_ms else None},
-                                'frac_of_own_roofs': at_roof_ms / hot_ms,
+                                'frac_of_own_roofs': at_roof_ms / hot_ms, 'floor_ms': floor_ms,
+                                'launches_per_step': sum(v[1] for v in per.values()) / len(sampled),
                                 'share_of_step': hot_ms / (1e3 * elapsed / args.steps),
                                 'kernels': {('%s%s' % (k[0], list(k[1]))): {'us': 1e3 * v[0] / v[1], 'n': v[1] / len(sampled),
                                                                            'GBps': algorithmic_bytes(k[0], k[1]) / (v[0] / v[1] * 1e-3) / 1e9,
                                                                            'bound': roofs[k]['bound'], 'frac_of_roof': roofs[k]['frac'],
+                                                                           'hbm_frac': roofs[k]['hbm_frac'], 'floor_us': roofs[k]['floor_us'],
+                                                                           'traffic': roofs[k]['traffic'],
                                                                            'valu_busy_pmc': roofs[k]['valu_busy_pmc']}
                                             for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line['cpu_baseline'] = cpu_baseline(args.workload, H, W)
+                line['cpu_baseline'] = cpu_baseline(args.workload, H, W, args.batch)
             except Exception as e:  # never lose the GPU number because the baseline leg failed
                 line['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(line))

@@ -68,6 +68,9 @@ const char* arflow_strerror(int code);
  * here.  Returns that hipError_t (0 = none) and clears the slot.  [No reference counterpart: the reference
  * checks cudaGetLastError() once after its launches, correlation_cuda_kernel.cu:383-392.] */
 int arflow_take_stale_error(void);
+/* Profiling aid: enqueues a one-wave no-op kernel (`af_marker_kernel`) that delimits the dispatches of consecutive calls in
+ * a rocprofv3 kernel / counter trace (tools/kbench.py, tools/pmc_calls.py).  [No reference counterpart.] */
+int arflow_profile_marker(int tag, arflow_stream_t stream);
 
 /* ---- cost volume ------------------------------------------------------------------------------
  * out[b, i*(2d+1)+j, y, x] = (1/C) sum_c x1[b,c,y,x] * x2[b,c,y+i-d,x+j-d], zero outside.

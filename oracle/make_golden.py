@@ -281,6 +281,25 @@ def gen_models():
     save('models', **out)
 
 
+def gen_models5():
+    """The 5-frame sliding-window pass of PWCLite (models/pwclite.py:274-281: windows (0,1,2), (1,2,3) and, with_bk,
+    (2,3,4)) through the REFERENCE model with deterministic weights -> tests/golden/models5.npz."""
+    import models.pwclite as mp
+    rng = torch.Generator().manual_seed(555)
+    frames = torch.cat([synth_pair(1, 128, 192, rng)[0] for _ in range(3)], 1)[:, :15]
+    u8 = (frames * 255).round().to(torch.uint8)
+    x = u8.float() / 255
+    # the window count comes from the INPUT (x.size(1) / 3, models/pwclite.py:261); the estimators are those of the 3-frame model
+    model = fill_deterministic(mp.PWCLite(Cfg(upsample=True, n_frames=3, reduce_dense=True))).eval()
+    res = model(x, with_bk=True)
+    out = {'x5': u8}
+    for k in ('flows_fw', 'flows_bw'):
+        for w, flows in enumerate(res[k]):
+            for i, f in enumerate(flows):
+                out['pwclite5_%s_%d_%d' % (k, w, i)] = pool_to_quarter(f, x.shape[2])
+    save('models5', **out)
+
+
 def gen_examples():
     """BASELINE config 1: the reference's example images (examples/img{0,1,2}.png, 1242x375) resized to
     384x640 as the README prescribes, through the reference PWCLite (2- and 3-frame) with deterministic
@@ -361,6 +380,8 @@ if __name__ == '__main__':
             gen_losses()
         if args.only in ('all', 'models'):
             gen_models()
+        if args.only in ('all', 'models5'):
+            gen_models5()
         if args.only in ('all', 'examples'):
             gen_examples()
         if args.only in ('all', 'general'):

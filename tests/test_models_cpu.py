@@ -57,3 +57,25 @@ def test_level_dropout_consumes_rng_like_the_reference():
         assert d[lvl, 3:].flatten().tolist() == [expect[1][lvl]] * 3
     m.eval()
     assert m._drops(2, 3, torch.device('cpu')) is None
+
+
+def test_pwclite_five_frame_windows_match_reference(golden):
+    """PWCLite.forward with 5 frames (models/pwclite.py:274-281): flows_fw = [window(0,1,2) 1->2, window(1,2,3) 2->3],
+    flows_bw = [window(1,2,3) 2->1, window(2,3,4) 3->2], each a finest-first list -- against the flows the REFERENCE
+    model produced for the same deterministic weights (tests/golden/models5.npz, oracle/make_golden.py::gen_models5)."""
+    from arflow_amd.config import AttrDict as C
+    g = golden('models5')
+    x = g['x5'].float() / 255
+    model = fill_deterministic(M.PWCLite(C(upsample=True, n_frames=3, reduce_dense=True))).eval()  # 3-frame estimators, 5 input frames
+    torch.set_num_threads(8)
+    with torch.no_grad(), oracle_ops(model):
+        res = model(x, with_bk=True)
+    for k in ('flows_fw', 'flows_bw'):
+        assert len(res[k]) == 2
+        for w, flows in enumerate(res[k]):
+            for i, f in enumerate(flows):
+                ref = g['pwclite5_%s_%d_%d' % (k, w, i)]
+                got = pool_to_quarter(f, x.shape[2])
+                assert got.shape == ref.shape
+                e = epe(got, ref)
+                assert e <= 1e-3, '5-frame %s window %d level %d: EPE %.3e px vs the reference' % (k, w, i, e)

@@ -56,7 +56,7 @@ def test_model_on_hip_ops_matches_reference(golden, case):
     flows = [torch.cat([a, b], 1) for a, b in zip(res['flows_fw'], res['flows_bw'])]
     lres = loss_fn(flows, x)
     ref_loss = float(g[tag + '_loss'])
-    assert abs(float(lres[0]) - ref_loss) <= 2e-4 * abs(ref_loss) + 1e-5, (float(lres[0]), ref_loss)
+    assert abs(float(lres[0].detach()) - ref_loss) <= 2e-4 * abs(ref_loss) + 1e-5, (float(lres[0].detach()), ref_loss)
     lres[0].backward()
     names = g[tag + '_gnames']
     gsum, gabs = g.raw(tag + '_gsum'), g.raw(tag + '_gabs')
@@ -192,6 +192,26 @@ def test_model_parameter_gradients_elementwise(tag, linear):
     l_gor, g_gor, _ = _param_grads(cls, cfg, x, 'cuda', False, linear)
     spread = _worst_rel(g_gor, g_cpu, names)[0]  # the oracle against itself across conv implementations
     w = _worst_rel(g_hip, g_gor, names)
-    bound = max(1e-3, 2.0 * spread)
+    # the run-time spread may widen the bound only up to a FIXED ceiling: a spread beyond the 2e-2 that was
+    # measured for these networks is itself a failure, and the bound never exceeds 4e-2 of max|g|
+    assert spread <= 2e-2, 'oracle GPU-vs-CPU spread %.3e exceeds the measured range (profiles/r02_grad_noise_leaky.log)' % spread
+    bound = min(max(1e-3, 2.0 * spread), 4e-2)
     assert w[0] <= bound, 'worst parameter gradient vs the oracle twin: %s differs by %.3e of its max (bound %.3e, ' \
                           'oracle GPU-vs-CPU spread %.3e)' % (w[1], w[0], bound, spread)
+
+
+def test_pwclite_five_frames_on_hip_ops(golden):
+    """5-frame sliding windows of PWCLite (models/pwclite.py:274-281) on the gfx950 kernels against the reference's flows
+    (tests/golden/models5.npz): EPE <= 1e-3 px at every level of every window."""
+    import arflow_amd.models as M
+    from arflow_amd.config import AttrDict as C
+    g = golden('models5')
+    x = (g['x5'].float() / 255).cuda()
+    model = fill_deterministic(M.PWCLite(C(upsample=True, n_frames=3, reduce_dense=True))).cuda().eval()
+    with torch.no_grad():
+        res = model(x, with_bk=True)
+    for k in ('flows_fw', 'flows_bw'):
+        for w, flows in enumerate(res[k]):
+            for i, f in enumerate(flows):
+                e = epe(pool_to_quarter(f, x.shape[2]), g['pwclite5_%s_%d_%d' % (k, w, i)])
+                assert e <= 1e-3, '5-frame %s window %d level %d: EPE %.3e px' % (k, w, i, e)

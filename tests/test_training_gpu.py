@@ -14,10 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_training_step_descends():
-    from arflow_amd.train_step import TrainStep
-    dev = torch.device('cuda')
-    torch.manual_seed(0)
+def _translated_pair(dev):
     g = torch.Generator().manual_seed(3)
     B, H, W, dx, dy = 4, 128, 192, 3, 2
     base = torch.rand(B, 3, (H + 16) // 8, (W + 16) // 8, generator=g)
@@ -25,13 +22,50 @@ def test_training_step_descends():
     tex = (tex + 0.1 * torch.rand(B, 3, H + 16, W + 16, generator=g)).clamp(0, 1)
     im1 = tex[:, :, 8:8 + H, 8:8 + W]
     im2 = tex[:, :, 8 - dy:8 - dy + H, 8 - dx:8 - dx + W]  # im2(p + (dx, dy)) = im1(p): forward flow = (+dx, +dy)
-    x = torch.cat([im1, im2], 1).contiguous().to(dev)
+    return torch.cat([im1, im2], 1).contiguous().to(dev)
+
+
+def test_training_step_descends():
+    """The whole backward (model on the HIP ops + UFlowLoss) yields a DESCENT direction, quantitatively: a plain gradient
+    step sized for a first-order decrease of 1e-3 of the loss lowers the loss by 0.3 .. 1.7 of that.  (Round 2 asserted
+    that the loss of 40 Adam steps falls by 1 %; at xavier initialisation the finest flows are ~40 px and the run is
+    chaotic -- it passed whenever the flows blew up into the all-occluded trivial minimum, loss 7.1 -> 0.008 in one step,
+    and failed otherwise.  Measured: tools/descend_probe.py.)  Then 10 Adam steps of the product TrainStep
+    (chairs_uflow.json: Adam 1e-4) must stay finite and move the parameters."""
+    from arflow_amd.train_step import TrainStep
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    x = _translated_pair(dev)
     step = TrainStep('pwclite_uflow+uflow_loss', dev, lr=1e-4, seed=1)  # Adam 1e-4: configs/chairs_uflow.json:29-48
     step.model.level_dropout = 0.0
-    losses = [float(step(x)) for _ in range(40)]
+    m = step.model
+
+    def loss_of():
+        out = m(x, with_bk=True)
+        flows = [torch.cat([a, b], 1) for a, b in zip(out['flows_fw'], out['flows_bw'])]
+        return step.loss(flows, x)[0]
+
+    params = [p for p in m.parameters() if p.requires_grad]
+    l0 = loss_of()
+    grads = torch.autograd.grad(l0, params, allow_unused=True)
+    g2 = sum(float((g.double() ** 2).sum()) for g in grads if g is not None)
+    assert g2 > 0 and l0 == l0
+    eps = 1e-3 * float(l0.detach()) / g2
+    with torch.no_grad():
+        for p, g in zip(params, grads):
+            if g is not None:
+                p.add_(g, alpha=-eps)
+        l1 = loss_of()
+        for p, g in zip(params, grads):
+            if g is not None:
+                p.add_(g, alpha=eps)
+    drop, predicted = float(l0.detach()) - float(l1), 1e-3 * float(l0.detach())
+    assert 0.3 * predicted <= drop <= 1.7 * predicted, 'gradient step: loss %.6f -> %.6f, drop %.3e vs first-order %.3e' % (
+        float(l0.detach()), float(l1), drop, predicted)
+    before = [p.detach().clone() for p in params[:4]]
+    losses = [float(step(x)) for _ in range(10)]
     assert all(l == l and abs(l) < 1e6 for l in losses), 'loss went non-finite'
-    first, last = sum(losses[:5]) / 5, sum(losses[-5:]) / 5
-    assert last < 0.99 * first, 'the unsupervised loss did not fall: %.4f -> %.4f' % (first, last)
+    assert any(float((a - p.detach()).abs().max()) > 0 for a, p in zip(before, params[:4])), 'Adam did not move the weights'
 
 
 def test_bench_self_launches_two_ranks():
@@ -44,10 +78,39 @@ def test_bench_self_launches_two_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and len(d['per_rank_ms_per_step']) == 2
+    assert d['n_gpus'] == 2 and d['collective_ranks'] == 2 and len(d['per_rank_ms_per_step']) == 2
     assert d['config']['global_batch'] == 4 and d['config']['loss_finite']
     assert d['collective_backend'] in ('nccl', 'gloo')
     assert d['oversubscribed'] == (torch.cuda.device_count() < 2)
+    # rccl_ranks counts ranks only when RCCL carried the all-reduce (a gloo rehearsal on a shared device reports 0)
+    assert d['rccl_ranks'] == (2 if d['collective_backend'] == 'nccl' else 0)
+
+
+def _bench_line(extra_env, steps=15, warmup=5):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(steps), '--warmup', str(warmup),
+                        '--no-cpu-baseline', '--no-kernel-timing'], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gradient_allreduce_over_rccl_world1():
+    """The RCCL path inside GPUTEST: bench.py as a fresh child with ARFLOW_FORCE_COLLECTIVES=1 runs the
+    bucketed gradient all-reduce (ddp.FlatGradAllReduce, the replacement of trainer/base_trainer.py:75 DataParallel) and,
+    with ARFLOW_GLOBAL_LOSS_NORM=1, the global loss normalisation (trainer/uflow_trainer.py:48-54) over backend 'nccl'
+    (= RCCL) at world size 1; the step must not cost more than 3 % over the plain single-process run (best of two)."""
+    plain = [_bench_line({})['ms_per_step'] for _ in range(2)]
+    d = _bench_line({'ARFLOW_FORCE_COLLECTIVES': '1', 'ARFLOW_GLOBAL_LOSS_NORM': '1'})
+    assert d['collective_backend'] == 'nccl' and d['rccl_ranks'] == 1 and d['collective_ranks'] == 1
+    assert d['global_loss_norm'] is True and d['config']['loss_finite']
+    d2 = _bench_line({'ARFLOW_FORCE_COLLECTIVES': '1', 'ARFLOW_GLOBAL_LOSS_NORM': '1'})
+    best = min(d['ms_per_step'], d2['ms_per_step'])
+    assert best <= 1.03 * min(plain), 'RCCL world-1 step %.2f ms vs plain %.2f ms' % (best, min(plain))
 
 
 def _worker_global_norm_gpu(rank, world, port, q):

@@ -21,8 +21,15 @@ def p(t):
     return None if t is None else t.data_ptr()
 
 
+MANIFEST = []  # (calls in the segment) per timed op, in launch order: tools/pmc_calls.py cuts the counter trace with it
+_marker = None
+
+
 def timeit(fn, iters):
     st = torch.cuda.current_stream()
+    if _marker is not None:
+        _marker(len(MANIFEST))  # one af_marker_kernel dispatch in front of every op's segment
+    MANIFEST.append({'name': None, 'shape': None, 'calls': 5 + iters})
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
@@ -44,10 +51,13 @@ def main():
     ap.add_argument('--levels', default='uflow')
     ap.add_argument('--batch', type=int, default=16, help='model-side batch (2B: both directions stacked)')
     ap.add_argument('--size', type=int, nargs=2, default=[384, 640])
+    ap.add_argument('--manifest', default='', help='write the ordered (name, shape, calls) list of the timed ops here')
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device('cuda')
     s = torch.cuda.current_stream().cuda_stream
+    global _marker
+    _marker = lambda tag: lib.arflow_profile_marker(int(tag), s)
     H0, W0 = args.size
     B2 = args.batch
     if args.levels == 'uflow':
@@ -62,6 +72,7 @@ def main():
         nb = algorithmic_bytes(name, shape)
         gbs = nb / us / 1e3
         rows.append((name, shape, us, gbs))
+        MANIFEST[-1].update(name=name, shape=list(shape), us=us)  # the segment timeit() has just run
         print('%-22s %-26s %9.1f us %9.1f GB/s  %5.1f%% of HBM peak' % (name, list(shape), us, gbs, 100 * gbs / HBM_PEAK_GBS), flush=True)
 
     def want(n):
@@ -92,6 +103,36 @@ def main():
             stt = torch.empty(B2, 4, device=dev)
             rec('arflow_featnorm_fwd', (B2, n), timeit(lambda: lib.arflow_featnorm_fwd(p(x1), p(x2), p(g1), p(g2), p(acc), p(stt), B2, n, 0, s), args.iters))
             rec('arflow_featnorm_bwd', (B2, n), timeit(lambda: lib.arflow_featnorm_bwd(p(x1), p(x2), p(x1), p(x2), p(stt), p(acc), p(g1), p(g2), B2, n, 0, s), args.iters))
+        if want('level'):
+            has_flow = (h, w) != (levels[0][1], levels[0][2])
+            fc = 0.7 * torch.randn(B2, 2, h // 2, w // 2, device=dev, generator=g) if has_flow else None
+            ctot = 81 + C + 2 + 32
+            buf = torch.zeros(B2, ctot, h, w, device=dev)
+            gbuf = torch.randn(B2, ctot, h, w, device=dev, generator=g)
+            bs = ctot * h * w
+            fup, x2w = torch.empty(B2, 2, h, w, device=dev), torch.empty_like(x2)
+            lsign = torch.zeros(B2, 3, h, w, device=dev, dtype=torch.int32)
+            lstats = torch.empty(B2, 4, device=dev)
+            lacc = torch.empty(4 * B2 * lib.arflow_level_acc_rows(B2, C, h, w, int(has_flow)), device=dev, dtype=torch.float64)
+            ws = torch.empty(lib.arflow_level_bwd_ws_bytes(B2, C, h, w), device=dev, dtype=torch.uint8)
+            gfc = torch.empty(B2, 2, h // 2, w // 2, device=dev)
+            gext = torch.randn(B2, 2, h, w, device=dev, generator=g)
+            vol, x1n, fslot = buf[:, :81], buf[:, 81:81 + C], buf[:, 81 + C:]
+            fk = 2 if has_flow else 0
+
+            def lfwd():
+                lib.arflow_level_fwd(p(x1), p(x2), p(fc), 2 * (h // 2) * (w // 2), int(has_flow), 1, p(fup) if has_flow else None,
+                                     fslot.data_ptr() if has_flow else None, bs, p(x2w) if has_flow else None, 0, vol.data_ptr(), bs,
+                                     x1n.data_ptr(), bs, p(lsign), p(lstats), p(lacc), B2, C, h, w, 4, 0.1, 0, 1, 0, s)
+
+            def lbwd():
+                lib.arflow_level_bwd(gbuf[:, :81].data_ptr(), bs, p(lsign), x1n.data_ptr(), bs, gbuf[:, 81:].data_ptr(), bs, p(x1),
+                                     p(x2), p(x2w) if has_flow else None, p(fup) if has_flow else None, 2 * h * w,
+                                     gbuf[:, 81 + C:].data_ptr() if has_flow else None, bs, p(gext) if has_flow else None,
+                                     p(lstats), 0, p(g1), p(g2), p(gfc) if has_flow else None, int(has_flow), 1, p(ws), B2, C, h,
+                                     w, 4, 0.1, 0, 1, 0, s)
+            rec('arflow_level_fwd', (B2, C, h, w, 4, 3, fk), timeit(lfwd, args.iters))
+            rec('arflow_level_bwd', (B2, C, h, w, 4, 3, fk), timeit(lbwd, args.iters))
     # loss side: B = batch/2 image pairs at full resolution, per direction
     B = max(1, B2 // 2)
     im1 = torch.rand(B, 3, H0, W0, device=dev, generator=g)
@@ -120,6 +161,8 @@ def main():
         maskw = torch.empty(B, 1, H0, W0, device=dev)
         gr1, gr2 = torch.empty(B, 1, H0, W0, device=dev), torch.empty(B, 1, H0, W0, device=dev)
         rec('arflow_down4_gray', (B, H0, W0), timeit(lambda: lib.arflow_down4_gray(p(im1), p(sm), p(gr1), B, H0, W0, s), args.iters))
+        _marker(len(MANIFEST))  # an untimed launch: its own (nameless) segment
+        MANIFEST.append({'name': None, 'shape': None, 'calls': 1})
         lib.arflow_down4_gray(p(im2), None, p(gr2), B, H0, W0, s)
         # a smooth flow (x4 bilinear upsample of a 2 px field, what the models emit) next to the white-noise one
         fls = torch.nn.functional.interpolate(fl2 * 2, scale_factor=4, mode='bilinear', align_corners=False).contiguous()
@@ -148,6 +191,8 @@ def main():
         rec('arflow_down4', (B * 3, H0, W0), timeit(lambda: lib.arflow_down4(p(im1), p(sm), B * 3, H0, W0, s), args.iters))
     if want('up4'):
         rec('arflow_up4_clamp_mul', (B, H0 // 4, W0 // 4), timeit(lambda: lib.arflow_up4_clamp_mul(p(sm), p(mask), p(dham), B, H0 // 4, W0 // 4, s), args.iters))
+    if args.manifest:
+        json.dump(MANIFEST, open(args.manifest, 'w'), indent=1)
     tot_us = sum(r[2] for r in rows)
     tot_b = sum(algorithmic_bytes(r[0], r[1]) for r in rows)
     print(json.dumps({'kernels': len(rows), 'sum_us': tot_us, 'sum_GB': tot_b / 1e9, 'aggregate_GBps': tot_b / tot_us / 1e3,
