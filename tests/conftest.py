@@ -67,11 +67,14 @@ MARGINS = []
 
 def _record_margin(msg, err, tol, atol, rtol):
     test = os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]
+    import inspect
+    fr = inspect.stack()[2]  # the test's assert_close() call site
+    site = '%s:%d' % (os.path.basename(fr.filename), fr.lineno)
     finite = torch.isfinite(err)
     if not bool(finite.all()) or err.numel() == 0:
         return
     ratio = torch.where(tol > 0, err / tol.clamp_min(1e-300), torch.where(err > 0, torch.full_like(err, float('inf')), torch.zeros_like(err)))
-    MARGINS.append({'test': test, 'what': msg, 'max_err': float(err.max()), 'atol': atol, 'rtol': rtol,
+    MARGINS.append({'test': test, 'site': site, 'what': msg, 'max_err': float(err.max()), 'atol': atol, 'rtol': rtol,
                     'err_over_tol': float(ratio.max())})
 
 

@@ -11,6 +11,12 @@ The launcher's choice of template instantiation depends on the tile count, so th
 corr_v2::fwd_kernel<2,1> / <4,1> / <2,4>, bwd_kernel<2,ACT> / <4,ACT> for ACT in {0,2}, warp_fwd_kernel<2>/<3>,
 the slab / list forms of the feature-warp gradient, featnorm's large-n path (n = 491 520) and the small one,
 census4 / photo4 at full resolution.  Tolerances are the stated fp32 ones of test_hip_parity.py.
+
+Tolerances (round 3): every assert_close() below was re-derived from the error MEASURED on MI355X -- tests/conftest.py
+records max(err / tol) per call site, profiles/r03_parity_margins.json holds the summary -- and sites that had more than
+20x headroom were divided down (the `/ N` factors and the small literals) so that each keeps about 10x over its measured
+error (float atomics and summation order move the error by 2-3x from run to run).  Sites left as they were sit within
+20x of their measured error already.
 """
 import pytest
 import torch
@@ -100,10 +106,10 @@ def test_feature_warp_at_bench_shapes(AF, O, cfg):
     a, f = cu(x).requires_grad_(True), cu(fl).requires_grad_(True)
     y = AF.warp(a, f, pad=pad, align_corners=ac)
     ulp = 2.0 ** -23 * max(H, W)
-    assert_close(y, ref, (2e-6 + 4 * ulp) * float(x.abs().max()), 1e-5, 'warp fwd')
+    assert_close(y, ref, ((2e-6 + 4 * ulp) * float(x.abs().max())) / 20, 5e-7, 'warp fwd')
     gx, gf = torch.autograd.grad(y, [a, f], cu(go))
-    assert_close(gx, rgx, 1e-5 * max(1.0, float(rgx.abs().max())), 1e-4, 'warp gsrc')
-    assert_close(gf, rgf, 1e-5 * (C ** 0.5) * float(x.abs().max()) * 4, 2e-4, 'warp gflow')
+    assert_close(gx, rgx, (1e-5 * max(1.0, float(rgx.abs().max()))) / 10, 1e-5, 'warp gsrc')
+    assert_close(gf, rgf, (1e-5 * (C ** 0.5) * float(x.abs().max()) * 4) / 20, 1e-5, 'warp gflow')
 
 
 def test_feature_warp_noisy_flow_at_bench_shape(AF, O):
@@ -117,8 +123,8 @@ def test_feature_warp_noisy_flow_at_bench_shape(AF, O):
     rgx, rgf = torch.autograd.grad(O.flow_warp(xr, fr), [xr, fr], go)
     a, f = cu(x).requires_grad_(True), cu(fl).requires_grad_(True)
     gx, gf = torch.autograd.grad(AF.warp(a, f), [a, f], cu(go))
-    assert_close(gx, rgx, 1e-5 * max(1.0, float(rgx.abs().max())), 1e-4, 'warp gsrc (noise)')
-    assert_close(gf, rgf, 1e-5 * (C ** 0.5) * float(x.abs().max()) * 4, 2e-4, 'warp gflow (noise)')
+    assert_close(gx, rgx, (1e-5 * max(1.0, float(rgx.abs().max()))) / 10, 1e-5, 'warp gsrc (noise)')
+    assert_close(gf, rgf, (1e-5 * (C ** 0.5) * float(x.abs().max()) * 4) / 20, 1e-5, 'warp gflow (noise)')
 
 
 @pytest.mark.parametrize('mode', ['joint', 'avg'])
@@ -137,12 +143,12 @@ def test_feature_normalisation_at_bench_shapes(AF, O, mode, shape):
     ra, rb = torch.autograd.grad([r1, r2], [a, b], [g1, g2])
     ac, bc = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
     y1, y2 = AF.normalize_pair(ac, bc, mode)
-    assert_close(y1, r1, 1e-5, 1e-5, 'y1')
-    assert_close(y2, r2, 1e-5, 1e-5, 'y2')
+    assert_close(y1, r1, 2e-6, 2e-6, 'y1')
+    assert_close(y2, r2, 5e-6, 5e-6, 'y2')
     da, db = torch.autograd.grad([y1, y2], [ac, bc], [cu(g1), cu(g2)])
     gt = max(float(ra.abs().max()), float(rb.abs().max()))
-    assert_close(da, ra, 2e-5 * gt, 1e-4, 'gx1')
-    assert_close(db, rb, 2e-5 * gt, 1e-4, 'gx2')
+    assert_close(da, ra, (2e-5 * gt) / 20, 5e-6, 'gx1')
+    assert_close(db, rb, (2e-5 * gt) / 20, 5e-6, 'gx2')
 
 
 def _pair(B, H, W, gen):
@@ -164,9 +170,9 @@ def test_census_loss_at_bench_shapes(O, size):
     rg, = torch.autograd.grad(ref, [b])
     bc = cu(im2).requires_grad_(True)
     y = U.census_loss(cu(im1), bc, cu(mask))
-    assert_close(y, ref, 1e-6, 1e-5, 'census loss')
+    assert_close(y, ref, 2e-7, 2e-6, 'census loss')
     gb, = torch.autograd.grad(y, [bc])
-    assert_close(gb, rg, 1e-4 * float(rg.abs().max()), 1e-4, 'census grad')
+    assert_close(gb, rg, (1e-4 * float(rg.abs().max())) / 20, 5e-6, 'census grad')
 
 
 @pytest.mark.parametrize('size', [(8, 384, 640), (4, 448, 1024)], ids=lambda s: 'x'.join(map(str, s)))
@@ -183,11 +189,11 @@ def test_photometric_sums_at_bench_shapes(AF, O, size):
     rg, = torch.autograd.grad(0.3 * l1 + 0.7 * ss, [rec])
     rc = cu(rec0).requires_grad_(True)
     s = AF.PhotoSumsFunction.apply(cu(im), rc, cu(mask))
-    assert_close(s[0], l1, 1e-3, 2e-5, 'sum |im - rec| mask')
-    assert_close(s[1], ss, 1e-3, 5e-5, 'sum SSIM distance')
-    assert_close(s[2], mask.sum(), 0, 1e-6, 'sum mask')
+    assert_close(s[0], l1, 5e-5, 1e-6, 'sum |im - rec| mask')
+    assert_close(s[1], ss, 0.0001, 5e-6, 'sum SSIM distance')
+    assert_close(s[2], mask.sum(), 0, 1e-7, 'sum mask')
     gg, = torch.autograd.grad(0.3 * s[0] + 0.7 * s[1], [rc])
-    assert_close(gg, rg, 1e-3 * float(rg.abs().max()), 1e-3, 'd / d recons')
+    assert_close(gg, rg, (1e-3 * float(rg.abs().max())) / 20, 5e-5, 'd / d recons')
 
 
 @pytest.mark.parametrize('size,order', [((2, 448, 1024), 1), ((2, 384, 640), 2), ((2, 256, 448), 1)],
@@ -215,9 +221,9 @@ def test_uflow_loss_end_to_end_at_bench_resolution(size, order):
     got = UFlowLoss(cfg)(fc, cu(img))
     names = ['total', 'census', 'smooth', '|flow|']
     for k in range(4):
-        assert_close(got[k], ref[k], 1e-6, 5e-5, 'uflow loss ' + names[k])
+        assert_close(got[k], ref[k], 5e-8, 3e-6, 'uflow loss ' + names[k])
     # the occlusion mask is a bilinear upsample of a clamped splat map times a validity mask: continuous
-    assert_close(got[4], ref[4], 2e-5, 1e-4, 'mask1')
+    assert_close(got[4], ref[4], 2e-6, 1e-5, 'mask1')
     gg = torch.autograd.grad(got[0], [fc[0], fc[2]])
     for a, b, n in zip(gg, rg, ('flow0', 'flow2')):
         assert_close(a, b, 2e-7 + 2e-4 * float(b.abs().max()), 2e-3, 'd loss / d ' + n)
@@ -245,7 +251,7 @@ def test_unflow_loss_end_to_end_at_bench_resolution():
     fc = [cu(f).requires_grad_(True) for f in flows]
     got = unFlowLoss(cfg)(fc, cu(img))
     for k in range(4):
-        assert_close(got[k], ref[k], 1e-6, 5e-5, 'unflow loss term %d' % k)
+        assert_close(got[k], ref[k], 2e-8, 1e-6, 'unflow loss term %d' % k)
     gg = torch.autograd.grad(got[0], fc[:5])
     for i, (a, b) in enumerate(zip(gg, rg)):
         assert_close(a, b, 2e-7 + 2e-4 * float(b.abs().max()), 2e-3, 'd loss / d flow%d' % i)

@@ -4,7 +4,13 @@
 
 Stated fp32 tolerances: correlation fwd/bwd atol 1e-6 (5e-6 with N(0,1) output
 gradients: 81 O(1) terms) rtol 1e-5; warp fwd atol (2e-6 + 4 ulp(coordinate)) * max|x|; warp bwd and
-splat maps (fp32 atomics, order-dependent) atol 1e-5 rtol 1e-4; scalar losses rtol 1e-5."""
+splat maps (fp32 atomics, order-dependent) atol 1e-5 rtol 1e-4; scalar losses rtol 1e-5.
+Tolerances (round 3): every assert_close() below was re-derived from the error MEASURED on MI355X -- tests/conftest.py
+records max(err / tol) per call site, profiles/r03_parity_margins.json holds the summary -- and sites that had more than
+20x headroom were divided down (the `/ N` factors and the small literals) so that each keeps about 10x over its measured
+error (float atomics and summation order move the error by 2-3x from run to run).  Sites left as they were sit within
+20x of their measured error already.
+"""
 import pytest
 import torch
 
@@ -92,7 +98,7 @@ def test_correlation_fused_leaky_relu(AF, oracle):
         g1, g2 = torch.autograd.grad(y, [ac, bc], cu(go))
         # a pre-activation within rounding of 0 may pick the other branch: compare away from it
         assert_close(g1, r1, 1e-5, 1e-4, 'fused leaky gx1')
-        assert_close(g2, r2, 1e-5, 1e-4, 'fused leaky gx2')
+        assert_close(g2, r2, 5e-6, 5e-5, 'fused leaky gx2')
 
 
 def test_correlation_bwd_derivative_from_output(AF, oracle):
@@ -116,19 +122,19 @@ def test_correlation_bwd_derivative_from_output(AF, oracle):
     _lib.check(lib.arflow_corr_bwd(goc.data_ptr(), out.data_ptr(), None, x1c.data_ptr(), x2c.data_ptr(), g1.data_ptr(),
                                    g2.data_ptr(), B, C, H, W, 4, 0.1, st), 'bwd')
     assert_close(out, ref, 1e-6, 1e-5, 'fwd')
-    assert_close(g1, r1, 1e-5, 1e-4, 'gx1 via out')
-    assert_close(g2, r2, 1e-5, 1e-4, 'gx2 via out')
+    assert_close(g1, r1, 5e-6, 5e-5, 'gx1 via out')
+    assert_close(g2, r2, 5e-6, 5e-5, 'gx2 via out')
 
 
 def test_feature_normalisation_golden(golden, AF):
     """Both normalize_features variants against the reference's outputs (tests/golden/aux.npz)."""
     g = golden('aux')
     a, b = AF.normalize_pair(cu(g['f1']), cu(g['f2']), 'joint')
-    assert_close(a, g['nj_1'], 2e-6, 1e-5, 'joint norm 1')
-    assert_close(b, g['nj_2'], 2e-6, 1e-5, 'joint norm 2')
+    assert_close(a, g['nj_1'], 4e-7, 2e-6, 'joint norm 1')
+    assert_close(b, g['nj_2'], 4e-7, 2e-6, 'joint norm 2')
     c, d = AF.normalize_pair(cu(g['f1']), cu(g['f2']), 'avg')
-    assert_close(c, g['nu_1'], 2e-6, 1e-5, 'uflow norm 1')
-    assert_close(d, g['nu_2'], 2e-6, 1e-5, 'uflow norm 2')
+    assert_close(c, g['nu_1'], 4e-7, 2e-6, 'uflow norm 1')
+    assert_close(d, g['nu_2'], 4e-7, 2e-6, 'uflow norm 2')
 
 
 @pytest.mark.parametrize('mode', ['joint', 'avg'])
@@ -149,17 +155,17 @@ def test_feature_normalisation_vs_oracle(AF, oracle, mode, shape, offset):
     y1, y2 = AF.normalize_pair(ac, bc, mode)
     # (x - mu) keeps the input's absolute rounding: atol scales with |x| / std
     tol = 2e-6 * (1.0 + abs(offset) * 4)
-    assert_close(y1, r1, tol * 4, 1e-5, 'y1')
-    assert_close(y2, r2, tol * 4, 1e-5, 'y2')
+    assert_close(y1, r1, (tol * 4) / 2, 5e-6, 'y1')
+    assert_close(y2, r2, (tol * 4) / 2, 5e-6, 'y2')
     da, db = torch.autograd.grad([y1, y2], [ac, bc], [cu(g1), cu(g2)])
     gt = max(float(ra.abs().max()), float(rb.abs().max()))
-    assert_close(da, ra, 2e-5 * gt * (1.0 + abs(offset)), 1e-4, 'gx1')
-    assert_close(db, rb, 2e-5 * gt * (1.0 + abs(offset)), 1e-4, 'gx2')
+    assert_close(da, ra, (2e-5 * gt * (1.0 + abs(offset))) / 20, 5e-6, 'gx1')
+    assert_close(db, rb, (2e-5 * gt * (1.0 + abs(offset))) / 20, 5e-6, 'gx2')
     # one-sided gradient request
     ac2 = cu(x1).requires_grad_(True)
     y1b, y2b = AF.normalize_pair(ac2, cu(x2), mode)
     da2, = torch.autograd.grad([y1b, y2b], [ac2], [cu(g1), cu(g2)])
-    assert_close(da2, ra, 2e-5 * gt * (1.0 + abs(offset)), 1e-4, 'gx1 only')
+    assert_close(da2, ra, (2e-5 * gt * (1.0 + abs(offset))) / 20, 5e-6, 'gx1 only')
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 24, 40), (3, 5, 3, 5), (1, 128, 6, 10), (2, 3, 96, 160)])
@@ -174,10 +180,10 @@ def test_bias_leaky_relu(AF, shape):
     ra, rb = torch.autograd.grad(ref, [a, bb], go)
     xc, bc = cu(x).requires_grad_(True), cu(bias).requires_grad_(True)
     y = AF.bias_leaky_relu(xc * 1.0, bc, 0.1)  # * 1.0: the op works in place on a non-leaf
-    assert_close(y, ref, 1e-6, 1e-6, 'fwd')
+    assert_close(y, ref, 1e-7, 1e-7, 'fwd')
     ga, gb = torch.autograd.grad(y, [xc, bc], cu(go))
-    assert_close(ga, ra, 1e-6, 1e-6, 'gx')
-    assert_close(gb, rb, 1e-5 * max(1.0, float(rb.abs().max())), 1e-5, 'gbias')
+    assert_close(ga, ra, 1e-7, 1e-7, 'gx')
+    assert_close(gb, rb, (1e-5 * max(1.0, float(rb.abs().max()))) / 2, 5e-6, 'gbias')
 
 
 def test_correlation_module_signature(AF):
@@ -225,7 +231,7 @@ def test_warp_backward_adversarial_fields(oracle, pad):
         sc, fc = cu(src).requires_grad_(True), cu(flow).requires_grad_(True)
         gs, gf = torch.autograd.grad(flow_warp(sc, fc, pad=pad, align_corners=True), [sc, fc], cu(go))
         assert_close(gs, r_s, 1e-5 * max(1.0, float(r_s.abs().max())), 1e-4, '%s %s gsrc' % (name, pad))
-        assert_close(gf, r_f, 1e-5 * max(1.0, float(r_f.abs().max())), 1e-4, '%s %s gflow' % (name, pad))
+        assert_close(gf, r_f, (1e-5 * max(1.0, float(r_f.abs().max()))) / 10, 1e-5, '%s %s gflow' % (name, pad))
 
 
 def test_flow_warp_golden(golden):
@@ -242,7 +248,7 @@ def test_flow_warp_golden(golden):
                 gx, gf = torch.autograd.grad(y, [x, fl], cu(g[name + '_g']))
                 assert_close(gx, g[tag + '_gx'], 1e-5, 1e-4, tag + ' gx')
                 if name != 'integer':  # at exactly-integer coordinates d/dflow is one-sided; see next test
-                    assert_close(gf, g[tag + '_gf'], 3e-5, 1e-4, tag + ' gflow')
+                    assert_close(gf, g[tag + '_gf'], 2e-5, 5e-5, tag + ' gflow')
 
 
 def test_resample_family_golden(golden):
@@ -257,13 +263,13 @@ def test_resample_family_golden(golden):
         assert_close(U.mask_invalid_flow(fl), g[name + '_mask_invalid'], 0, 0, name + ' mask_invalid_flow')
         tol = _warp_tol(x.detach(), *x.shape[2:])
         y = U.resample(x, coords)
-        assert_close(y, g[name + '_resample_y'], tol, 1e-5, name + ' resample')
+        assert_close(y, g[name + '_resample_y'], (tol) / 10, 1e-6, name + ' resample')
         gx, gf = torch.autograd.grad(y, [x, fl], cu(g[name + '_g']))
-        assert_close(gx, g[name + '_resample_gx'], 1e-5, 1e-4, name + ' resample gx')
+        assert_close(gx, g[name + '_resample_gx'], 5e-7, 5e-6, name + ' resample gx')
         if name != 'integer':
-            assert_close(gf, g[name + '_resample_gf'], 3e-5, 1e-4, name + ' resample gflow')
+            assert_close(gf, g[name + '_resample_gf'], 3e-6, 1e-5, name + ' resample gflow')
         y2 = U.resample_flow(x, fl)
-        assert_close(y2, g[name + '_resample_y'], tol, 1e-5, name + ' resample_flow')
+        assert_close(y2, g[name + '_resample_y'], (tol) / 10, 1e-6, name + ' resample_flow')
         nhwc = R.resampler(x.detach().permute(0, 2, 3, 1).contiguous(), coords.detach().permute(0, 2, 3, 1).contiguous())
         assert_close(nhwc, g[name + '_resampler_nhwc'], tol + 2e-6, 1e-5, name + ' resampler nhwc')
 
@@ -281,11 +287,11 @@ def test_flow_warp_vs_oracle(AF, oracle, cfg):
     rgx, rgf = torch.autograd.grad(ref, [xr, fr], go)
     a, f = cu(x).requires_grad_(True), cu(fl).requires_grad_(True)
     y = AF.warp(a, f, pad=pad, align_corners=ac)
-    assert_close(y, ref, _warp_tol(x, H, W), 1e-5, 'warp fwd')
+    assert_close(y, ref, (_warp_tol(x, H, W)) / 50, 2e-7, 'warp fwd')
     gx, gf = torch.autograd.grad(y, [a, f], cu(go))
-    assert_close(gx, rgx, 2e-5, 1e-4, 'warp gx')
+    assert_close(gx, rgx, 4e-6, 2e-5, 'warp gx')
     # d/dflow multiplies sums over C channels by up to W/2: scale the absolute tolerance with it
-    assert_close(gf, rgf, 1e-5 * (C ** 0.5) * float(x.abs().max()) * 4, 2e-4, 'warp gflow')
+    assert_close(gf, rgf, (1e-5 * (C ** 0.5) * float(x.abs().max()) * 4) / 20, 1e-5, 'warp gflow')
 
 
 def test_warp_strided_flow_and_flow_only_grad(AF, oracle):
@@ -300,9 +306,9 @@ def test_warp_strided_flow_and_flow_only_grad(AF, oracle):
         rg, = torch.autograd.grad(ref, [fr], torch.ones_like(ref))
         f4c = cu(f4).requires_grad_(True)
         y = AF.warp(cu(x), f4c[:, sl], pad='zeros', align_corners=True, norm=AF.NORM_UFLOW)
-        assert_close(y, ref, 1e-5, 1e-5, 'strided warp')
+        assert_close(y, ref, 1e-6, 1e-6, 'strided warp')
         g, = torch.autograd.grad(y, [f4c], torch.ones_like(y))
-        assert_close(g[:, sl], rg, 1e-4, 2e-4, 'strided gflow')
+        assert_close(g[:, sl], rg, 5e-6, 1e-5, 'strided gflow')
         other = slice(2, 4) if sl.start == 0 else slice(0, 2)
         assert float(g[:, other].abs().max()) == 0.0
 
@@ -312,11 +318,11 @@ def test_masks_golden(golden):
     g = golden('masks')
     for name in g.names():
         fl = cu(g[name + '_flow'])
-        assert_close(U.compute_range_map(fl), g[name + '_range_map'], 1e-5, 1e-4, name + ' range map')
-        assert_close(WU.compute_range_map(fl), g[name + '_range_map_wu'], 1e-5, 1e-4, name + ' range map wu')
+        assert_close(U.compute_range_map(fl), g[name + '_range_map'], 2e-6, 2e-5, name + ' range map')
+        assert_close(WU.compute_range_map(fl), g[name + '_range_map_wu'], 2e-6, 2e-5, name + ' range map wu')
         coords = U.flow_to_warp(fl)
-        assert_close(WU.get_corresponding_map(coords), g[name + '_corr_map'], 1e-5, 1e-4, name + ' corr map')
-        assert_close(WU.get_occu_mask_backward(fl, th=0.0), g[name + '_occ_back_0'], 1e-5, 1e-4, name + ' occ soft')
+        assert_close(WU.get_corresponding_map(coords), g[name + '_corr_map'], 2e-6, 2e-5, name + ' corr map')
+        assert_close(WU.get_occu_mask_backward(fl, th=0.0), g[name + '_occ_back_0'], 5e-6, 5e-5, name + ' occ soft')
         # thresholded masks: compare where the reference's soft value is not within 1e-5 of the threshold
         soft = 1.0 - g[name + '_occ_back_0']
         safe = (soft - 0.2).abs() > 1e-5
@@ -348,13 +354,13 @@ def test_photo_blocks_golden(golden):
         a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
         y = LB.SSIM(a, b)
         # sigma = E[x^2]-mu^2 cancels against C2 = 9e-4: fp32 summation-order noise is amplified ~1e3x
-        assert_close(y, g[name + '_ssim'], 5e-5, 1e-5, name + ' ssim')
+        assert_close(y, g[name + '_ssim'], 5e-6, 1e-6, name + ' ssim')
         ga, gb = torch.autograd.grad(y, [a, b], cu(g[name + '_ssim_g']))
         # relative to the gradient's scale: 2e-4 of max|ref| (the window variances cancel against C2 = 9e-4, which
         # amplifies fp32 summation-order noise ~1e2 on the flattest windows) + 1e-3 of the element
         for got_, key in ((ga, '_ssim_ga'), (gb, '_ssim_gb')):
             ref_ = g[name + key]
-            assert_close(got_, ref_, 2e-4 * float(ref_.abs().max()), 1e-3, name + key)
+            assert_close(got_, ref_, (2e-4 * float(ref_.abs().max())) / 2, 0.0005, name + key)
         for md, sd in ((1, False), (3, True)):
             tag = '%s_ternary_%d_%d' % (name, md, int(sd))
             a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
@@ -364,30 +370,30 @@ def test_photo_blocks_golden(golden):
             ga, gb = torch.autograd.grad(dist, [a, b], cu(g[tag + '_g']))
             for got_, key in ((ga, '_ga'), (gb, '_gb')):  # relative to the gradient's scale, not an absolute number
                 ref_ = g[tag + key]
-                assert_close(got_, ref_, 1e-4 * float(ref_.abs().max()), 2e-4, tag + key)
+                assert_close(got_, ref_, (1e-4 * float(ref_.abs().max())) / 20, 1e-5, tag + key)
         for ps in (7, 3):
             b = im2.clone().requires_grad_(True)
             y = U.census_loss(im1, b, mask, ps)
-            assert_close(y, g['%s_census_%d' % (name, ps)], 1e-6, 1e-5, name + ' census')
+            assert_close(y, g['%s_census_%d' % (name, ps)], 5e-7, 5e-6, name + ' census')
             gb, = torch.autograd.grad(y, [b])
             ref = g['%s_census_%d_gb' % (name, ps)]
-            assert_close(gb, ref, 1e-6 + 1e-4 * float(ref.abs().max()), 1e-4, name + ' census gb')
+            assert_close(gb, ref, (1e-6 + 1e-4 * float(ref.abs().max())) / 20, 5e-6, name + ' census gb')
         for fn, key in ((lambda f: LB.smooth_grad_1st(f, im1, 10.), 'sm1_abs'),
                         (lambda f: LB.smooth_grad_1st(f, im1, 10., penalty='uflow'), 'sm1_uflow'),
                         (lambda f: LB.smooth_grad_2nd(f, im1, 10.), 'sm2')):
             f = fl.clone().requires_grad_(True)
             y = fn(f)
-            assert_close(y, g['%s_%s' % (name, key)], 1e-7, 1e-5, name + ' ' + key)
+            assert_close(y, g['%s_%s' % (name, key)], 2e-8, 2e-6, name + ' ' + key)
             gf, = torch.autograd.grad(y, [f])
             ref = g['%s_%s_gf' % (name, key)]
-            assert_close(gf, ref, 1e-8 + 1e-5 * float(ref.abs().max()), 1e-4, name + ' ' + key + ' grad')
+            assert_close(gf, ref, (1e-8 + 1e-5 * float(ref.abs().max())) / 10, 1e-5, name + ' ' + key + ' grad')
 
 
 def test_resize_helpers_golden(golden, AF):
     g = golden('aux')
-    assert_close(AF.down4(cu(g['img'])), g['down4'], 1e-6, 1e-5, 'down4')
+    assert_close(AF.down4(cu(g['img'])), g['down4'], 1e-7, 1e-6, 'down4')
     up = AF.up4_clamp_mul(cu(g['m']))
-    assert_close(up, g['up4'], 1e-6, 1e-5, 'up4 (inputs already in [0,1])')
+    assert_close(up, g['up4'], 2e-7, 2e-6, 'up4 (inputs already in [0,1])')
 
 
 def _loss_cases():
@@ -406,12 +412,12 @@ def test_loss_modules_golden(golden, group):
     for name, cfg in cases:
         flows = [cu(g['flow%d' % i]).requires_grad_(True) for i in range(5)]
         res = cls(AttrDict(cfg))(flows, img)
-        assert_close(res[0], g[name + '_total'], 1e-6, 5e-5, name + ' total')
-        assert_close(res[1], g[name + '_warp'], 1e-6, 5e-5, name + ' warp')
-        assert_close(res[2], g[name + '_smooth'], 1e-6, 5e-5, name + ' smooth')
-        assert_close(res[3], g[name + '_absflow'], 1e-6, 1e-5, name + ' |flow|')
+        assert_close(res[0], g[name + '_total'], 5e-8, 3e-6, name + ' total')
+        assert_close(res[1], g[name + '_warp'], 5e-8, 3e-6, name + ' warp')
+        assert_close(res[2], g[name + '_smooth'], 2e-8, 1e-6, name + ' smooth')
+        assert_close(res[3], g[name + '_absflow'], 1e-7, 1e-6, name + ' |flow|')
         if len(res) > 4:
-            assert_close(res[4], g[name + '_mask1'], 1e-5, 1e-4, name + ' mask1')
+            assert_close(res[4], g[name + '_mask1'], 1e-6, 1e-5, name + ' mask1')
         grads = torch.autograd.grad(res[0], flows, allow_unused=True)
         for i, gi in enumerate(grads):
             ref = g['%s_g%d' % (name, i)]
@@ -431,9 +437,9 @@ def test_census_vs_oracle_midsize(oracle):
     rg, = torch.autograd.grad(ref, [b])
     bc = cu(im2).requires_grad_(True)
     y = U.census_loss(cu(im1), bc, cu(mask))
-    assert_close(y, ref, 1e-6, 1e-5, 'census loss')
+    assert_close(y, ref, 2e-7, 2e-6, 'census loss')
     gb, = torch.autograd.grad(y, [bc])
-    assert_close(gb, rg, 1e-4 * float(rg.abs().max()), 1e-4, 'census grad')
+    assert_close(gb, rg, (1e-4 * float(rg.abs().max())) / 20, 5e-6, 'census grad')
 
 
 def test_full_size_properties(AF):
@@ -447,7 +453,7 @@ def test_full_size_properties(AF):
     # shifting x2 by one pixel moves the volume one displacement channel
     x2s = torch.roll(x2, shifts=1, dims=3)
     ys = AF.correlation(x1, x2s, 4)
-    assert_close(ys[:, 41, :, 8:-8], y[:, 40, :, 8:-8], 1e-6, 1e-5, 'shift equivariance')
+    assert_close(ys[:, 41, :, 8:-8], y[:, 40, :, 8:-8], 1e-7, 1e-6, 'shift equivariance')
     # linearity in x1
     y2 = AF.correlation(2.5 * x1, x2, 4)
     assert_close(y2, 2.5 * y, 1e-6, 1e-5, 'linearity')
@@ -509,10 +515,10 @@ def test_mv_loss_vs_oracle():
     c10 = [cu(f).requires_grad_(True) for f in f10]
     got = MvLoss(cfg)(c12, c10, cu(img))
     for k in range(4):
-        assert_close(got[k], ref[k], 1e-6, 1e-4, 'mv loss term %d' % k)
+        assert_close(got[k], ref[k], 1e-8, 1e-6, 'mv loss term %d' % k)
     gg = torch.autograd.grad(got[0], c12 + c10)
     for a, b in zip(gg, rg):
-        assert_close(a, b, 2e-7 + 2e-4 * float(b.abs().max()), 2e-3, 'mv dflow')
+        assert_close(a, b, (2e-7 + 2e-4 * float(b.abs().max())) / 10, 0.0002, 'mv dflow')
 
 
 def test_random_shapes_fuzz(AF, oracle):
@@ -557,17 +563,17 @@ def test_random_shapes_fuzz(AF, oracle):
         sc, fc = cu(x2).requires_grad_(True), cu(flow).requires_grad_(True)
         wy = flow_warp(sc, fc, pad=pad, align_corners=ac_)
         tol = (2e-6 + 4 * 2.0 ** -23 * max(H, W)) * max(1.0, float(x2.abs().max()))
-        assert_close(wy, wr, tol, 1e-5, tag + ' warp')
+        assert_close(wy, wr, (tol) / 20, 5e-7, tag + ' warp')
         gs, gf = torch.autograd.grad(wy, [sc, fc], cu(gw))
-        assert_close(gs, rs, 1e-5 * max(1.0, float(rs.abs().max())), 1e-4, tag + ' warp gsrc')
-        assert_close(gf, rf, 2e-4 * max(1.0, float(rf.abs().max())), 1e-3, tag + ' warp gflow')
+        assert_close(gs, rs, (1e-5 * max(1.0, float(rs.abs().max()))) / 20, 5e-6, tag + ' warp gsrc')
+        assert_close(gf, rf, (2e-4 * max(1.0, float(rf.abs().max()))) / 200, 5e-6, tag + ' warp gflow')
         # splat map, feature normalisation
-        assert_close(compute_range_map(cu(flow)), oracle.compute_range_map(flow), 1e-5, 1e-4, tag + ' range map')
+        assert_close(compute_range_map(cu(flow)), oracle.compute_range_map(flow), 2e-6, 2e-5, tag + ' range map')
         if C * H * W >= 2:
             ya, yb = AF.normalize_pair(cu(x1), cu(x2), 'joint')
             ra, rb = oracle.normalize_features_joint([x1, x2])
-            assert_close(ya, ra, 1e-5, 1e-5, tag + ' norm')
-            assert_close(yb, rb, 1e-5, 1e-5, tag + ' norm')
+            assert_close(ya, ra, 2e-6, 2e-6, tag + ' norm')
+            assert_close(yb, rb, 2e-6, 2e-6, tag + ' norm')
         # census loss and smoothness on 3-channel images (the reference's zero_mask_border,
         # utils/uflow_utils.py:234-238, breaks on maps smaller than its 3-pixel border: H, W >= 7 only)
         im1, im2 = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, 3, H, W, generator=gen)
@@ -581,7 +587,7 @@ def test_random_shapes_fuzz(AF, oracle):
             if float(mask[:, :, 3:-3, 3:-3].sum()) > 0:
                 gr, = torch.autograd.grad(lr, i2)
                 gc, = torch.autograd.grad(lc, i2c)
-                assert_close(gc, gr, 2e-5 * max(1e-3, float(gr.abs().max())), 2e-4, tag + ' census grad')
+                assert_close(gc, gr, (2e-5 * max(1e-3, float(gr.abs().max()))) / 5, 4e-5, tag + ' census grad')
         if H >= 2 and W >= 2:
             fl = flow.clone().requires_grad_(True)
             sr = oracle.smooth_grad_1st(fl, im1, 10.0)
@@ -590,7 +596,7 @@ def test_random_shapes_fuzz(AF, oracle):
             assert abs(float(sc_) - float(sr)) <= 2e-5 * abs(float(sr)) + 1e-7, (tag, float(sc_), float(sr))
             gsr, = torch.autograd.grad(sr, fl)
             gsc, = torch.autograd.grad(sc_, flc)
-            assert_close(gsc, gsr, 1e-6 + 1e-5 * float(gsr.abs().max()), 1e-4, tag + ' smooth grad')
+            assert_close(gsc, gsr, (1e-6 + 1e-5 * float(gsr.abs().max())) / 100, 1e-6, tag + ' smooth grad')
 
 
 @pytest.mark.parametrize('sym', ['0', '1'], ids=['ordered', 'pair-symmetric'])
@@ -625,7 +631,7 @@ def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, sym, mon
     l2, mask2 = AF.census_warp_loss(gray1, gray2, f2, cu(occ), 7)
     g2, = torch.autograd.grad(l2, [f2])
     assert torch.equal(mask1, mask2), 'mask differs from the unfused path'
-    assert_close(l2, l1, 1e-6, 1e-5, 'loss vs the unfused path')
+    assert_close(l2, l1, 5e-7, 5e-6, 'loss vs the unfused path')
     assert_close(g2, g1, 1e-6 + 1e-4 * float(g1.abs().max()), 1e-3, 'flow gradient vs the unfused path')
     # oracle
     fr = flow.clone().requires_grad_(True)
@@ -635,7 +641,7 @@ def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, sym, mon
     lr = oracle.census_loss(im1, oracle.resample(im2, coords), rmask.detach())
     gr, = torch.autograd.grad(lr, [fr])
     assert_close(mask2, rmask, 1e-6, 1e-6, 'mask vs oracle')
-    assert_close(l2, lr, 1e-6, 1e-5, 'loss vs oracle')
+    assert_close(l2, lr, 5e-7, 5e-6, 'loss vs oracle')
     assert_close(g2, gr, 1e-6 + 1e-4 * float(gr.abs().max()), 1e-3, 'flow gradient vs oracle')
     # without the occlusion term (occ_small = NULL): mask = validity only
     l3, mask3 = AF.census_warp_loss(gray1, gray2, cu(flow), None, 7)
@@ -674,7 +680,7 @@ def test_correlation_concat_equals_cat_of_plain_op(AF, oracle, shape, slope):
     assert_close(y, yr, 1e-6, 1e-5, 'concat with shared x1')
     q1, q2 = torch.autograd.grad(yr, [r1, r2], cu(go[:, :81 + C]))
     assert_close(g1, q1, 1e-5, 1e-4, 'gx1 (corr + identity paths)')
-    assert_close(g2, q2, 1e-5, 1e-4, 'gx2')
+    assert_close(g2, q2, 5e-6, 5e-5, 'gx2')
 
 
 @pytest.mark.parametrize('shape', [(2, 32, 24, 40), (1, 7, 17, 33), (16, 32, 96, 160)], ids=lambda s: 'x'.join(map(str, s)))
@@ -699,7 +705,7 @@ def test_bf16_storage_correlation(AF, oracle, shape, slope):
     a, b = cu(x1).requires_grad_(True), cu(x2).requires_grad_(True)
     y = AF.correlation(a, b, 4, negative_slope=slope, storage='bf16')
     assert y.dtype == torch.float32
-    assert_close(y, ref, 1e-6, 1e-5, 'bf16-storage corr fwd')
+    assert_close(y, ref, 5e-7, 5e-6, 'bf16-storage corr fwd')
     g1, g2 = torch.autograd.grad(y, [a, b], cu(go))
     assert g1.dtype == torch.float32
     assert_close(g1, q1, 5e-6, 1e-5, 'bf16-storage corr gx1')
@@ -724,11 +730,11 @@ def test_bf16_storage_warp(AF, oracle, cfg):
     a, f = cu(x).requires_grad_(True), cu(fl).requires_grad_(True)
     y = flow_warp(a, f, pad=pad, align_corners=ac, storage_dtype=torch.bfloat16)
     ulp = 2.0 ** -23 * max(H, W)
-    assert_close(y, ref, (2e-6 + 4 * ulp) * float(x.abs().max()), 1e-5, 'bf16-storage warp fwd')
+    assert_close(y, ref, ((2e-6 + 4 * ulp) * float(x.abs().max())) / 20, 5e-7, 'bf16-storage warp fwd')
     gx, gf = torch.autograd.grad(y, [a, f], cu(go))
     assert gx.dtype == torch.float32
-    assert_close(gx, rgx, 1e-5 * max(1.0, float(rgx.abs().max())), 1e-4, 'bf16-storage warp gsrc')
-    assert_close(gf, rgf, 1e-5 * (C ** 0.5) * float(x.abs().max()) * 4, 2e-4, 'bf16-storage warp gflow')
+    assert_close(gx, rgx, (1e-5 * max(1.0, float(rgx.abs().max()))) / 10, 1e-5, 'bf16-storage warp gsrc')
+    assert_close(gf, rgf, (1e-5 * (C ** 0.5) * float(x.abs().max()) * 4) / 20, 1e-5, 'bf16-storage warp gflow')
 
 
 def test_general_parameter_space_golden(golden):
@@ -754,11 +760,11 @@ def test_general_parameter_space_golden(golden):
     for md in (2, 3):
         a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
         y = LB.SSIM(a, b, md=md)
-        assert_close(y, g['ssim%d' % md], 5e-5, 1e-5, 'ssim md=%d' % md)
+        assert_close(y, g['ssim%d' % md], 5e-6, 1e-6, 'ssim md=%d' % md)
         ga, gb = torch.autograd.grad(y, [a, b], cu(g['ssim%d_g' % md]))
         for got_, key in ((ga, 'ssim%d_ga' % md), (gb, 'ssim%d_gb' % md)):
             ref_ = g[key]
-            assert_close(got_, ref_, 2e-4 * float(ref_.abs().max()), 1e-3, key)
+            assert_close(got_, ref_, (2e-4 * float(ref_.abs().max())) / 50, 2e-5, key)
     for md, sd in ((4, True), (5, False)):
         tag = 'tern%d_%d' % (md, int(sd))
         a, b = im1.clone().requires_grad_(True), im2.clone().requires_grad_(True)
@@ -768,7 +774,7 @@ def test_general_parameter_space_golden(golden):
         ga, gb = torch.autograd.grad(dist, [a, b], cu(g[tag + '_g']))
         for got_, key in ((ga, '_ga'), (gb, '_gb')):
             ref_ = g[tag + key]
-            assert_close(got_, ref_, 1e-4 * float(ref_.abs().max()), 2e-4, tag + key)
+            assert_close(got_, ref_, (1e-4 * float(ref_.abs().max())) / 20, 1e-5, tag + key)
 
 
 @pytest.mark.parametrize('cfg', [(4, 1, 4, 1, 1), (3, 3, 2, 2, 2), (20, 1, 20, 1, 2), (2, 1, 4, 1, 1), (5, 3, 4, 2, 1)],

@@ -8,6 +8,12 @@ behind arflow_amd.functional.level) against the CPU oracle chain the reference r
 at the launch shapes of BASELINE configs 2, 3 and 4.  Tolerances (fp32, written per assertion): the upsampled flow
 differs from ATen's CPU kernel by <= 2 ulp of |flow|; through the warp that moves a sampled feature by (slope of the
 feature map) x 2 ulp(coordinate), which is why the quantities behind the warp carry a tolerance relative to max|x|.
+
+Tolerances (round 3): every assert_close() below was re-derived from the error MEASURED on MI355X -- tests/conftest.py
+records max(err / tol) per call site, profiles/r03_parity_margins.json holds the summary -- and sites that had more than
+20x headroom were divided down (the `/ N` factors and the small literals) so that each keeps about 10x over its measured
+error (float atomics and summation order move the error by 2-3x from run to run).  Sites left as they were sit within
+20x of their measured error already.
 """
 import pytest
 import torch
@@ -103,7 +109,7 @@ def test_level_forward_backward_vs_oracle(AF, O, shape, mode):
         # ATen's CPU kernel and this one round the same four products in a different order: <= 2 ulp of |flow|
         assert_close(flow, ref_flow, 4e-7 * max(fmax, 1.0), 0, 'flow_up ' + tag)
         assert_close(buf[:, 81 + C:81 + C + 2], ref_flow, 4e-7 * max(fmax, 1.0), 0, 'flow slot ' + tag)
-    assert_close(buf[:, 81:81 + C], ref_buf[:, 81:81 + C], 2e-6, 1e-5, 'x1n ' + tag)
+    assert_close(buf[:, 81:81 + C], ref_buf[:, 81:81 + C], 1e-6, 5e-6, 'x1n ' + tag)
     # volume: O(1) values; behind the warp (see the module docstring)
     vol_tol = 2e-6 + (2e-5 * xmax if has_flow else 0.0)
     assert_close(buf[:, :81], ref_buf[:, :81], vol_tol, 1e-5, 'volume ' + tag)
@@ -180,7 +186,7 @@ def test_level_uflow_layout(AF, O, shape):
     buf, fu = AF.level(a, b, fc, cfg, cx, a)
     fmax = float(flow.detach().abs().max())
     assert_close(fu, flow, 4e-7 * max(fmax, 1.0), 0, 'flow_up')
-    assert_close(buf[:, 8:8 + 81], ref[:, 8:8 + 81], 2e-6 + 2e-5 * float(x2.detach().abs().max()), 1e-5, 'volume')
+    assert_close(buf[:, 8:8 + 81], ref[:, 8:8 + 81], (2e-6 + 2e-5 * float(x2.detach().abs().max())) / 2, 5e-6, 'volume')
     assert_close(buf[:, :6], ctx, 0, 0, 'context copy')
     assert_close(buf[:, -C:], x1, 0, 0, 'features1 copy')
     got = torch.autograd.grad((buf * gbuf.cuda()).sum() + (fu * gflow.cuda()).sum(), [a, b, fc, cx])
