@@ -108,3 +108,14 @@ def check(code, what):
     if code != 0:
         msg = load().arflow_strerror(code)
         raise ArflowHipError('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', code))
+
+
+def poll_stale_error(lib, what):
+    """A HIP error that was ALREADY pending when an entry point was entered (left by the framework or by an unchecked
+    earlier call) is moved into a process-wide slot by the library (csrc/common.hpp af_clear_stale_error) instead of being
+    blamed on -- or silently cleared by -- our launch.  Read and clear that slot after every call and surface it."""
+    code = lib.arflow_take_stale_error()
+    if code:
+        import warnings
+        warnings.warn('a HIP error (hipError_t %d) was pending when %s was called: it comes from an earlier call of '
+                      'another library on this thread, not from arflow_amd' % (code, what), RuntimeWarning, stacklevel=3)

@@ -10,25 +10,30 @@ from . import functional as AF
 
 
 class Correlation(nn.Module):
-    def __init__(self, pad_size=None, kernel_size=1, max_displacement=4, stride1=1, stride2=1,
-                 corr_multiply=1, storage_dtype=None, **kwargs):
-        """storage_dtype=torch.bfloat16 (opt-in, not in the reference's signature): keep the features as bf16 in
-        HBM -- fp32 accumulation, fp32 volume and gradients."""
+    def __init__(self, max_displacement=4, *args, pad_size=None, kernel_size=1, stride1=1, stride2=1, corr_multiply=1,
+                 storage_dtype=None, **kwargs):
+        """Signature of models/correlation_native.py:7 -- ``max_displacement`` first, further POSITIONAL arguments swallowed
+        like there (``Correlation(3)`` is the d = 3 volume) -- with the keyword arguments every model passes
+        (models/pwclite.py:124-125: pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply).
+        correlation_native ignores those keywords; here a NON-default (pad_size, kernel_size, stride1, stride2) is
+        honoured with the semantics of the CUDA extension the keywords come from (correlation_cuda.cc:10-16; parity
+        unpinned), and ``pad_size`` / ``output_dim`` describe the volume actually computed.
+        storage_dtype=torch.bfloat16 (opt-in, not in the reference's signature): keep the features as bf16 in
+        HBM -- fp32 accumulation, fp32 volume and gradients: footprint only, not speed."""
         super().__init__()
         self.storage = storage_dtype
-        if pad_size is None:
-            pad_size = max_displacement
-        # models/correlation_native.py:7 swallows these arguments and always computes the (pad=d, kernel=1, stride=1)
-        # volume; the CUDA extension (correlation_cuda.cc:10-16) honours them.  Every model uses the default, which runs
-        # the tuned kernels; anything else runs the general kernels with the extension's semantics.
-        self.general = None
-        if (kernel_size, stride1, stride2) != (1, 1, 1) or pad_size != max_displacement:
-            if kernel_size % 2 != 1:
-                raise ValueError('kernel_size must be odd')
-            self.general = (int(pad_size), int(kernel_size), int(max_displacement), int(stride1), int(stride2))
         self.max_displacement = int(max_displacement)
+        if pad_size is None:
+            pad_size = self.max_displacement
+        self.general = None
         self.output_dim = 2 * self.max_displacement + 1
         self.pad_size = self.max_displacement
+        if (kernel_size, stride1, stride2) != (1, 1, 1) or pad_size != self.max_displacement:
+            if kernel_size % 2 != 1:
+                raise ValueError('kernel_size must be odd')
+            self.general = (int(pad_size), int(kernel_size), self.max_displacement, int(stride1), int(stride2))
+            self.pad_size = int(pad_size)
+            self.output_dim = 2 * (self.max_displacement // int(stride2)) + 1  # displacements per axis (correlation_cuda.cc:31-34)
 
     def forward(self, x1, x2, negative_slope=1.0):
         """``negative_slope`` != 1 fuses the LeakyReLU the callers apply to the volume

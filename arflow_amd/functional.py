@@ -102,6 +102,7 @@ def _call(name, *args, key=None):
     else:
         rc = getattr(lib, name)(*args)
     _lib.check(rc, name)
+    _lib.poll_stale_error(lib, name)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -85,3 +85,40 @@ def test_product_package_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_stale_error_slot_is_polled_and_cleared(lib):
+    """the slot a pending foreign HIP error is parked in must be read (and so cleared) by the Python layer after
+    every call, and surfaced -- checked here with a stand-in library object (no GPU needed)."""
+    import warnings
+    from arflow_amd import _lib
+    lib.arflow_take_stale_error()  # (a GPU-less host may have parked hipErrorNoDevice from the calls of the tests above)
+    assert lib.arflow_take_stale_error() == 0  # reading clears the slot
+
+    class Fake:
+        def __init__(self):
+            self.code, self.reads = 719, 0
+
+        def arflow_take_stale_error(self):
+            self.reads += 1
+            c, self.code = self.code, 0
+            return c
+    fake = Fake()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        _lib.poll_stale_error(fake, 'arflow_corr_fwd')
+        _lib.poll_stale_error(fake, 'arflow_corr_fwd')
+    assert fake.reads == 2 and len(w) == 1 and '719' in str(w[0].message)
+    import inspect
+    from arflow_amd import functional
+    assert 'poll_stale_error' in inspect.getsource(functional._call)
+
+
+def test_correlation_signature_follows_correlation_native():
+    from arflow_amd.correlation import Correlation
+    c = Correlation(3)  # models/correlation_native.py:7: max_displacement is the first positional argument
+    assert c.max_displacement == 3 and c.output_dim == 7 and c.pad_size == 3 and c.general is None
+    c = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)  # models/pwclite.py:124
+    assert c.general is None and c.output_dim == 9
+    c = Correlation(pad_size=3, kernel_size=3, max_displacement=2, stride1=1, stride2=2)
+    assert c.general == (3, 3, 2, 1, 2) and c.pad_size == 3 and c.output_dim == 3
