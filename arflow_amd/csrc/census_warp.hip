@@ -118,7 +118,10 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ gray_
                                                  const float* __restrict__ flow, long fbs,
                                                  const float* __restrict__ occ_small, float* __restrict__ mask_out,
                                                  float* __restrict__ dham_out, float* __restrict__ sums, int nrows,
-                                                 int nimg, int H, int W) {
+                                                 int nimg, int H, int W, int pair) {
+  // pair: the batch interleaves the two DIRECTIONS of UFlowLoss (sample s = 2 b + dir; losses/uflow_loss.py:30-54 runs them
+  // one after the other): image b of sample s is plane s ^ 1 of `gray_b` (= gray_a), its range map plane s ^ 1 of
+  // `occ_small`, and the partial sums of direction 1 go to columns 2, 3 of the row instead of 0, 1.
   __shared__ __attribute__((aligned(16))) float ga[ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float gb[ROWS * PITCH];
   __shared__ float red[2 * (NT / 64)];
@@ -130,8 +133,9 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ gray_
   const int ty0 = bty * TYH, tx0 = btx * TXW;
   const long cs = (long)H * W;
   const float* fl = flow + b * fbs;
+  const int bp = pair ? (b ^ 1) : b;
   zero_margins<R>(gb);
-  load_gray_warped<R>(gb, gray_b + b * cs, fl, H, W, ty0, tx0);
+  load_gray_warped<R>(gb, gray_b + bp * cs, fl, H, W, ty0, tx0);
   load_plane<R>(ga, gray_a + b * cs, H, W, ty0, tx0);
   __syncthreads();
   const int xg = threadIdx.x & 15, ly = threadIdx.x >> 4;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ gray_
     const float4 fu = *reinterpret_cast<const float4*>(fl + o);
     const float4 fv = *reinterpret_cast<const float4*>(fl + cs + o);
     const float uu[4] = {fu.x, fu.y, fu.z, fu.w}, vv[4] = {fv.x, fv.y, fv.z, fv.w};
-    const float* occ = occ_small ? occ_small + (long)b * (H / 4) * (W / 4) : nullptr;
+    const float* occ = occ_small ? occ_small + (long)bp * (H / 4) * (W / 4) : nullptr;
     float mv[4], dh[4];
     const bool rowin = y >= R && y < H - R;
 #pragma unroll
@@ -186,14 +190,19 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ gray_
     *reinterpret_cast<float4*>(dham_out + (long)b * cs + o) = make_float4(dh[0], dh[1], dh[2], dh[3]);
   }
   af_block_sum<2>(part, red);
-  if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
+  if (threadIdx.x == 0) {
+    if (pair && (b & 1))
+      af_store_partial(sums, nrows, 0.f, 0.f, part[0], part[1]);
+    else
+      af_store_partial(sums, nrows, part[0], part[1], 0.f);
+  }
 }
 
 template <int R>
 __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ gray_a, const float* __restrict__ gray_b,
                                                  const float* __restrict__ flow, long fbs,
                                                  const float* __restrict__ dham, const float* __restrict__ scale,
-                                                 float* __restrict__ gflow, int nimg, int H, int W) {
+                                                 float* __restrict__ gflow, int nimg, int H, int W, int pair) {
   __shared__ __attribute__((aligned(16))) float ga[ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float gb[ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float gg[ROWS * PITCH];
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ gray_
   const int ty0 = bty * TYH, tx0 = btx * TXW;
   const long cs = (long)H * W;
   const float* fl = flow + b * fbs;
-  const float* sb = gray_b + b * cs;
+  const float* sb = gray_b + (pair ? (b ^ 1) : b) * cs;
   zero_margins<R>(gb);
   load_gray_warped<R>(gb, sb, fl, H, W, ty0, tx0);
   load_plane<R>(ga, gray_a + b * cs, H, W, ty0, tx0);
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ gray_
   }
   // d loss / d grey_b(p) = sc * acc (census4::bwd_kernel's value before the colour weights; the x255 lives in the
   // grey plane), times the warp's flow gradient
-  const float sc = (scale ? scale[0] : 1.f) * (0.1f * -2.f * 0.81f);
+  const float sc = (scale ? scale[pair ? (b & 1) : 0] : 1.f) * (0.1f * -2.f * 0.81f);  // pair: one scale per direction
   float* gf = gflow + (long)b * 2 * cs + o;
   *reinterpret_cast<float4*>(gf) =
       make_float4(sc * acc[0] * cdx[0], sc * acc[1] * cdx[1], sc * acc[2] * cdx[2], sc * acc[3] * cdx[3]);
@@ -331,9 +340,9 @@ extern "C" int arflow_down4_gray(const float* im, float* small, float* gray, int
   return af_launch_status();
 }
 
-extern "C" int arflow_census_warp_fwd(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
-                                      const float* occ_small, float* mask_out, float* dham, float* sums, int B, int H,
-                                      int W, int radius, arflow_stream_t stream) {
+static int census_warp_fwd_impl(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
+                                const float* occ_small, float* mask_out, float* dham, float* sums, int B, int H,
+                                int W, int radius, arflow_stream_t stream, int pair) {
   af_clear_stale_error();
   AF_REQUIRE_PTR(gray_a);
   AF_REQUIRE_PTR(gray_b);
@@ -346,20 +355,36 @@ extern "C" int arflow_census_warp_fwd(const float* gray_a, const float* gray_b, 
   AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
   const int nrows = af_sums_rows(B, H, W);
-  if (use_sym()) return census_sym_fwd(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, radius, st);
+  if (use_sym() && !pair) return census_sym_fwd(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, radius, st);
   namespace cw = census_warp;
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B));
   switch (radius) {
-    case 1: hipLaunchKernelGGL(cw::fwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W); break;
-    case 2: hipLaunchKernelGGL(cw::fwd_kernel<2>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W); break;
-    default: hipLaunchKernelGGL(cw::fwd_kernel<3>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W); break;
+    case 1: hipLaunchKernelGGL(cw::fwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, pair); break;
+    case 2: hipLaunchKernelGGL(cw::fwd_kernel<2>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, pair); break;
+    default: hipLaunchKernelGGL(cw::fwd_kernel<3>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, pair); break;
   }
   return af_launch_status();
 }
 
-extern "C" int arflow_census_warp_bwd(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
-                                      const float* dham, const float* scale, float* gflow, int B, int H, int W,
-                                      int radius, arflow_stream_t stream) {
+extern "C" int arflow_census_warp_fwd(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
+                                      const float* occ_small, float* mask_out, float* dham, float* sums, int B, int H,
+                                      int W, int radius, arflow_stream_t stream) {
+  return census_warp_fwd_impl(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, B, H, W, radius, stream, 0);
+}
+// Both directions of UFlowLoss in one launch: B = 2 x image pairs, sample s = 2 b + direction (what the model's [B,4,H,W]
+// (fw, bw) flow tensor IS when viewed as [2B,2,H,W], and the [B,6,H,W] image pair viewed as [2B,3,H,W]); `gray` holds the 2B
+// grey planes: image a of sample s is plane s, image b plane s ^ 1; occ_small plane s ^ 1 masks sample s; sums columns
+// (0,1) belong to direction 0, (2,3) to direction 1; `scale` of the backward holds one factor per direction.
+extern "C" int arflow_census_warp_pair_fwd(const float* gray, const float* flow, long flow_bstride, const float* occ_small,
+                                           float* mask_out, float* dham, float* sums, int B2, int H, int W, int radius,
+                                           arflow_stream_t stream) {
+  AF_REQUIRE(B2 % 2 == 0, ARFLOW_ESHAPE);
+  return census_warp_fwd_impl(gray, gray, flow, flow_bstride, occ_small, mask_out, dham, sums, B2, H, W, radius, stream, 1);
+}
+
+static int census_warp_bwd_impl(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
+                                const float* dham, const float* scale, float* gflow, int B, int H, int W,
+                                int radius, arflow_stream_t stream, int pair) {
   af_clear_stale_error();
   AF_REQUIRE_PTR(gray_a);
   AF_REQUIRE_PTR(gray_b);
@@ -371,13 +396,26 @@ extern "C" int arflow_census_warp_bwd(const float* gray_a, const float* gray_b, 
   AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
   AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
   hipStream_t st = (hipStream_t)stream;
-  if (use_sym()) return census_sym_bwd(gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, radius, st);
+  if (use_sym() && !pair) return census_sym_bwd(gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, radius, st);
   namespace cw = census_warp;
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B));
   switch (radius) {
-    case 1: hipLaunchKernelGGL(cw::bwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W); break;
-    case 2: hipLaunchKernelGGL(cw::bwd_kernel<2>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W); break;
-    default: hipLaunchKernelGGL(cw::bwd_kernel<3>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W); break;
+    case 1: hipLaunchKernelGGL(cw::bwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, pair); break;
+    case 2: hipLaunchKernelGGL(cw::bwd_kernel<2>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, pair); break;
+    default: hipLaunchKernelGGL(cw::bwd_kernel<3>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, pair); break;
   }
   return af_launch_status();
+}
+
+extern "C" int arflow_census_warp_bwd(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
+                                      const float* dham, const float* scale, float* gflow, int B, int H, int W,
+                                      int radius, arflow_stream_t stream) {
+  return census_warp_bwd_impl(gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, radius, stream, 0);
+}
+extern "C" int arflow_census_warp_pair_bwd(const float* gray, const float* flow, long flow_bstride, const float* dham,
+                                           const float* scale2, float* gflow, int B2, int H, int W, int radius,
+                                           arflow_stream_t stream) {
+  AF_REQUIRE(B2 % 2 == 0, ARFLOW_ESHAPE);
+  AF_REQUIRE_PTR(scale2);
+  return census_warp_bwd_impl(gray, gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, radius, stream, 1);
 }

@@ -91,10 +91,11 @@ __device__ __forceinline__ void af_block_sum(float (&v)[NV], float* scratch) {
 // rows is defined and the caller adds them all -- no zero-fill launch, no atomics, and a result that does not depend
 // on the order workgroups finish in.  (Round 1: hipMemsetAsync + atomicAdd into 256 slotted rows -- the memset was
 // a separate ~4 us GPU operation in front of every reduction.)  nrows >= number of workgroups, host-checked.
-__device__ __forceinline__ void af_store_partial(float* __restrict__ sums, int nrows, float a, float b, float c) {
+__device__ __forceinline__ void af_store_partial(float* __restrict__ sums, int nrows, float a, float b, float c,
+                                                 float d = 0.f) {
   const int nwg = gridDim.x * gridDim.y * gridDim.z;
   const int w = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  *reinterpret_cast<float4*>(sums + (long)w * ARFLOW_SUM_COLS) = make_float4(a, b, c, 0.f);
+  *reinterpret_cast<float4*>(sums + (long)w * ARFLOW_SUM_COLS) = make_float4(a, b, c, d);
   for (int r = w + nwg; r < nrows; r += nwg)
     *reinterpret_cast<float4*>(sums + (long)r * ARFLOW_SUM_COLS) = make_float4(0.f, 0.f, 0.f, 0.f);
 }

@@ -815,6 +815,54 @@ class CensusWarpLossFunction(torch.autograd.Function):
         return None, None, gflow, None, None
 
 
+class CensusWarpPairLossFunction(torch.autograd.Function):
+    """BOTH photometric directions of UFlowLoss (losses/uflow_loss.py:30-54) as ONE launch each way.  The batch holds
+    2B samples s = 2 b + direction: ``gray2`` the grey planes (x255) of the [B,6,H,W] pair viewed as [2B,3,H,W], ``flow2``
+    the [B,4,H,W] (fw, bw) flows viewed as [2B,2,H,W], ``occ_small2`` the range maps of the 2B level-2 flows (sample s is
+    masked by plane s ^ 1).  Returns (loss fw, loss bw, mask [2B,1,H,W]); gradient w.r.t. the flows only."""
+
+    @staticmethod
+    def forward(ctx, gray2, flow2, occ_small2, patch_size):
+        _need_gpu(gray2, flow2, occ_small2)
+        gray2 = gray2.detach().contiguous()
+        flow2, fbs = _flow_view(flow2)
+        B2, C, H, W = gray2.shape
+        if C != 1 or B2 % 2 or flow2.shape != (B2, 2, H, W):
+            raise ValueError('census_warp_pair_loss expects [2B,1,H,W] grey planes and [2B,2,H,W] flows')
+        occ_small2 = occ_small2.detach().contiguous()
+        if occ_small2.shape != (B2, 1, H // 4, W // 4):
+            raise ValueError('occ_small2 must be the [2B,1,H/4,W/4] range maps')
+        r = int(patch_size) // 2
+        buf = _new_sums(gray2.device, B2, H, W)
+        dham = torch.empty(B2, 1, H, W, device=gray2.device, dtype=torch.float32)
+        mask = torch.empty(B2, 1, H, W, device=gray2.device, dtype=torch.float32)
+        with torch.cuda.device_of(gray2):
+            _call('arflow_census_warp_pair_fwd', _p(gray2), _p(flow2), fbs, _p(occ_small2), _p(mask), _p(dham), _p(buf), B2, H,
+                  W, r, _stream(), key=(B2, H, W))
+        sums = _fold_sums(buf, 4)
+        den = torch.stack([_ddp.global_denominator(sums[1]), _ddp.global_denominator(sums[3])]) + 1e-6 / _ddp.world_size()
+        inv = 1.0 / den
+        ctx.save_for_backward(gray2, flow2, dham, inv)
+        ctx.r, ctx.fbs = r, fbs
+        ctx.mark_non_differentiable(mask)
+        return sums[0] * inv[0], sums[2] * inv[1], mask
+
+    @staticmethod
+    def backward(ctx, g0, g1, gmask_unused):
+        gray2, flow2, dham, inv = ctx.saved_tensors
+        B2, _, H, W = gray2.shape
+        scale = (torch.stack([g0.reshape(()), g1.reshape(())]) * inv).contiguous()
+        gflow = torch.empty(B2, 2, H, W, device=gray2.device, dtype=torch.float32)
+        with torch.cuda.device_of(gray2):
+            _call('arflow_census_warp_pair_bwd', _p(gray2), _p(flow2), ctx.fbs, _p(dham), _p(scale), _p(gflow), B2, H, W, ctx.r,
+                  _stream(), key=(B2, H, W))
+        return None, gflow, None, None
+
+
+def census_warp_pair_loss(gray2, flow2, occ_small2, patch_size=7):
+    return CensusWarpPairLossFunction.apply(gray2, flow2, occ_small2, patch_size)
+
+
 def census_warp_supported(H, W):
     return bool(_lib.load().arflow_census_warp_supported(int(H), int(W)))
 

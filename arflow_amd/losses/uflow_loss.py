@@ -1,7 +1,10 @@
 """UFlowLoss on the gfx950 kernels -- same constructor, inputs and 5-tuple result as
 losses/uflow_loss.py:8-109.
 
-Per step: one launch per image for its x1/4 copy + grey plane (arflow_down4_gray); per direction: 1 splat launch
+Per step (with_bk, the usual case): BOTH directions as one pass over 2B samples -- 1 launch for the x1/4 copies + grey planes
+of both images, 1 splat launch (level-2 range maps), 1 launch for warp + validity mask + clamp/x4 upsample + census loss
+(arflow_census_warp_pair_fwd; one launch backward) and 1 fused smoothness launch (`_both_directions`).  Otherwise, per
+direction: one launch per image for its x1/4 copy + grey plane (arflow_down4_gray); 1 splat launch
 (level-2 range map), ONE launch for warp + validity mask + clamp/x4 upsample of the range map + census loss
 (arflow_census_warp_fwd; its backward is one launch too) and 1 fused smoothness launch; the reference issues ~150
 ATen kernels and ~25 full-resolution 49-channel temporaries for the same work.
@@ -18,6 +21,7 @@ class UFlowLoss(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.fused = True  # False: the unfused photometric path (warp, mask upsample and census as separate launches)
+        self.pair = True   # False: the two directions one after the other (the reference's order)
 
     def _smooth(self, flow_ab2, im_small):
         cfg = self.cfg
@@ -56,8 +60,35 @@ class UFlowLoss(nn.Module):
             gray = None
         return {'im': im, 'small': small, 'gray': gray}
 
+    def _both_directions(self, output, target):
+        """with_bk, as ONE pass over a batch of 2B samples s = 2 b + direction: [B,4,h,w] flows ARE [2B,2,h,w], the
+        [B,6,H,W] pair IS [2B,3,H,W] (views, no copy); sample s reads its second image / its occlusion map from its
+        partner s ^ 1.  1 + 1 + 1 + 1 launches forward (grey + x1/4 copy, range maps, census, smoothness) and 1 + 1
+        backward for what the per-direction path issues twice; the smoothness term only needs the directions' sum."""
+        cfg = self.cfg
+        B, _, H, W = target.shape
+        h, w = output[2].shape[2:]
+        small, gray = AF.down4_gray(target.view(2 * B, 3, H, W))
+        f0, f2 = output[0].view(2 * B, 2, H, W), output[2].view(2 * B, 2, h, w)
+        occ = AF.splat_map(f2, 0)
+        l_fw, l_bw, mask = AF.census_warp_pair_loss(gray, f0, occ, 7)
+        loss_warp = cfg.w_census * l_fw + cfg.w_census * l_bw
+        order = int(cfg.smooth_order)
+        if order not in (1, 2):
+            raise NotImplementedError('smooth_order must be 1 or 2')
+        s = AF.smooth_sums(f2, small, 1.0, float(cfg.edge_constant), order, 1, 1)
+        nx, ny = float(B * 2 * h * (w - order)), float(B * 2 * (h - order) * w)  # elements per DIRECTION
+        loss_smooth = cfg.w_smooth * (s[0] / nx + s[1] / ny) / 2.
+        return loss_warp + loss_smooth, loss_warp, loss_smooth, output[0].abs().mean(), mask.view(B, 2, 1, H, W)[:, 0]
+
     def forward(self, output, target):
         """output: list of [B,4,h,w] (fw,bw) flows, finest first; target: [B,6,H,W] image pair."""
+        H, W = target.shape[2:]
+        if (self.fused and self.pair and self.cfg.with_bk and target.is_cuda and target.is_contiguous()
+                and output[0].is_contiguous() and output[2].is_contiguous() and output[0].shape[1] == 4
+                and H % 4 == 0 and W % 4 == 0 and AF.census_warp_supported(H, W)
+                and tuple(output[2].shape[2:]) == (H // 4, W // 4)):
+            return self._both_directions(output, target)
         f12_0, f21_0 = output[0][:, 0:2], output[0][:, 2:4]
         f12_2, f21_2 = output[2][:, 0:2], output[2][:, 2:4]
         one, two = self._prepare(target[:, :3]), self._prepare(target[:, 3:])

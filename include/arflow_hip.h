@@ -277,6 +277,17 @@ int arflow_census_warp_fwd(const float* gray_a, const float* gray_b, const float
 int arflow_census_warp_bwd(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,
                            const float* dham, const float* scale, float* gflow, int B, int H, int W, int radius,
                            arflow_stream_t stream);
+/* Both directions of UFlowLoss (losses/uflow_loss.py:30-54 runs them one after the other) in ONE launch each way: the batch
+ * holds B2 = 2 x image pairs, sample s = 2 b + direction -- the model's [B,4,H,W] (fw, bw) flow tensor viewed as [2B,2,H,W]
+ * and the [B,6,H,W] image pair viewed as [2B,3,H,W].  `gray`: the 2B grey planes (arflow_down4_gray on that view): image a
+ * of sample s is plane s, image b plane s ^ 1; occ_small plane s ^ 1 (range map of the partner direction's level-2 flow)
+ * masks sample s.  sums: columns (0, 1) = (sum loss, sum mask) of direction 0, (2, 3) of direction 1.  scale2: two
+ * factors, one per direction. */
+int arflow_census_warp_pair_fwd(const float* gray, const float* flow, long flow_bstride, const float* occ_small,
+                                float* mask_out, float* dham, float* sums, int B2, int H, int W, int radius,
+                                arflow_stream_t stream);
+int arflow_census_warp_pair_bwd(const float* gray, const float* flow, long flow_bstride, const float* dham,
+                                const float* scale2, float* gflow, int B2, int H, int W, int radius, arflow_stream_t stream);
 /* gray[B,1,H,W] = rgb_to_grayscale(im) * 255 (utils/uflow_utils.py:227-231) and, if small != NULL,
  * small[B,3,H/4,W/4] = downsample(im, x1/4) as arflow_down4 (losses/uflow_loss.py:59-60) from the same read.
  * im: [B,3,H,W], H % 4 == 0, W % 4 == 0. */

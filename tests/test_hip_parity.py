@@ -804,3 +804,28 @@ def test_general_correlation_parameters(oracle, cfg):
     if cfg == (4, 1, 4, 1, 1):
         assert m.general is None  # the default set runs the tuned kernels
         assert_close(y, oracle.correlation(x1, x2, 4), 1e-6, 1e-5, 'default == correlation_native')
+
+
+def test_uflow_loss_both_directions_in_one_pass_equals_sequential():
+    """UFlowLoss with_bk: the one-pass form over 2B (image pair, direction) samples (arflow_census_warp_pair_*) against the
+    per-direction form (the reference's order, losses/uflow_loss.py:30-54): same losses, mask and flow gradients."""
+    from arflow_amd.config import AttrDict
+    from arflow_amd.losses import UFlowLoss
+    from oracle.fixture_common import synth_pair
+    gen = torch.Generator().manual_seed(21)
+    B, H, W = 3, 64, 96
+    img = synth_pair(B, H, W, gen)[0].cuda()
+    flows = [(3.0 / s) * torch.randn(B, 4, H // s, W // s, generator=gen).cuda() for s in (1, 2, 4)]
+    res = {}
+    for pair in (True, False):
+        loss = UFlowLoss(AttrDict(edge_constant=150, w_smooth=4.0, w_census=1.0, with_bk=True, smooth_order=1))
+        loss.pair = pair
+        f = [t.clone().requires_grad_(True) for t in flows]
+        out = loss(f, img)
+        g = torch.autograd.grad(out[0], [f[0], f[2]])
+        res[pair] = ([o.detach() for o in out], g)
+    for k, n in enumerate(['total', 'census', 'smooth', '|flow|']):
+        assert_close(res[True][0][k], res[False][0][k], 1e-7, 2e-6, 'pair vs sequential ' + n)
+    assert_close(res[True][0][4], res[False][0][4], 0, 0, 'mask1')
+    for a, b, n in zip(res[True][1], res[False][1], ('d flow0', 'd flow2')):
+        assert_close(a, b, 1e-7 * float(b.abs().max()) + 1e-12, 1e-5, n)
