@@ -283,11 +283,15 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ gray_
 // grey plane (x255) of an RGB image and, optionally, its bilinear x1/4 copy (align_corners=False on a multiple-of-4
 // grid = the mean of the central 2 x 2 of every 4 x 4 block, as down4_kernel of smooth.hip): one thread per 4 x 4
 // block, every load and store a float4.
+// zero (nullable): a [B, H/4, W/4] plane cleared by the same launch (the range-map accumulation target of the splat that
+// follows: saves its fill launch)
 __global__ __launch_bounds__(256) void down4_gray_kernel(const float* __restrict__ im, float* __restrict__ small,
-                                                        float* __restrict__ gray, int H, int W) {
+                                                        float* __restrict__ gray, int H, int W,
+                                                        float* __restrict__ zero = nullptr) {
   const int h = H / 4, w = W / 4;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
   if (x >= w) return;
+  if (zero) zero[((long)b * h + y) * w + x] = 0.f;
   const long cs = (long)H * W;
   const float* p = im + (long)b * 3 * cs + (long)(4 * y) * W + 4 * x;
   float4 px[3][4];
@@ -330,14 +334,18 @@ static bool use_sym() {
 
 extern "C" int arflow_census_warp_supported(int H, int W) { return (W % 4 == 0 && H % 4 == 0 && H >= 8 && W >= 8) ? 1 : 0; }
 
-extern "C" int arflow_down4_gray(const float* im, float* small, float* gray, int B, int H, int W, arflow_stream_t stream) {
+extern "C" int arflow_down4_gray_z(const float* im, float* small, float* gray, float* zero_plane, int B, int H, int W,
+                                   arflow_stream_t stream) {
   af_clear_stale_error();
   AF_REQUIRE_PTR(im);
   AF_REQUIRE_PTR(gray);
   AF_REQUIRE(B > 0 && B <= 65535 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && H / 4 <= 65535, ARFLOW_ESHAPE);
   hipLaunchKernelGGL(census_warp::down4_gray_kernel, dim3(af_cdiv(W / 4, 256), H / 4, B), dim3(256), 0,
-                     (hipStream_t)stream, im, small, gray, H, W);
+                     (hipStream_t)stream, im, small, gray, H, W, zero_plane);
   return af_launch_status();
+}
+extern "C" int arflow_down4_gray(const float* im, float* small, float* gray, int B, int H, int W, arflow_stream_t stream) {
+  return arflow_down4_gray_z(im, small, gray, nullptr, B, H, W, stream);
 }
 
 static int census_warp_fwd_impl(const float* gray_a, const float* gray_b, const float* flow, long flow_bstride,

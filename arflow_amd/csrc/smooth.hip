@@ -10,70 +10,9 @@
 // reads hit L1/L2 and HBM sees each tensor once.  The reference runs ~12 elementwise ATen kernels
 // plus 2 reductions per direction; here it is one launch forward and one backward.
 #include "common.hpp"
+#include "smooth_dev.hpp"
 
 namespace {
-
-struct SmoothArgs {
-  const float* flow;
-  const float* img;
-  int Ci, H, W;
-  long fbs;
-  float fscale, alpha;
-  int order, wmode, penalty;
-};
-
-__device__ __forceinline__ float pen(float v, int penalty) {
-  return penalty == 0 ? fabsf(v) : sqrtf(fmaf(v, v, 1e-6f));
-}
-__device__ __forceinline__ float dpen(float v, int penalty) {
-  if (penalty == 0) return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
-  return v / sqrtf(fmaf(v, v, 1e-6f));
-}
-
-// Sum over channels of |I(p) - I(q)| with the element offsets p, q inside one plane.  CI > 0: the channel
-// count is a compile-time constant (3 for every caller) and all 2*CI loads are issued before the first
-// use; CI == 0 keeps the runtime loop.  (With the runtime loop hipcc waits for each pair of loads: a
-// dozen serialised round trips per pixel made the full-resolution launches latency-bound.)
-template <int CI>
-__device__ __forceinline__ float chan_absdiff(const SmoothArgs& a, const float* ib, long p, long q) {
-  const long cs = (long)a.H * a.W;
-  float s = 0.f;
-  if (CI > 0) {
-    float u[CI > 0 ? CI : 1], v[CI > 0 ? CI : 1];
-#pragma unroll
-    for (int c = 0; c < CI; ++c) u[c] = ib[c * cs + p], v[c] = ib[c * cs + q];
-#pragma unroll
-    for (int c = 0; c < CI; ++c) s += fabsf(u[c] - v[c]);
-  } else {
-    for (int c = 0; c < a.Ci; ++c) s += fabsf(ib[c * cs + p] - ib[c * cs + q]);
-  }
-  return s;
-}
-// edge weight for the x-difference anchored at (y,x); caller guarantees validity.
-template <int CI>
-__device__ __forceinline__ float edge_wx(const SmoothArgs& a, const float* ib, int y, int x) {
-  const int xa = a.order == 1 ? x + 1 : x + 2;
-  const int xb = a.order == 1 ? x : (a.wmode == 0 ? x + 1 : x);
-  const float s = chan_absdiff<CI>(a, ib, (long)y * a.W + xa, (long)y * a.W + xb);
-  return __expf(-(s / (float)a.Ci) * a.alpha);
-}
-template <int CI>
-__device__ __forceinline__ float edge_wy(const SmoothArgs& a, const float* ib, int y, int x) {
-  const int ya = a.order == 1 ? y + 1 : y + 2;
-  const int yb = a.order == 1 ? y : (a.wmode == 0 ? y + 1 : y);
-  const float s = chan_absdiff<CI>(a, ib, (long)ya * a.W + x, (long)yb * a.W + x);
-  return __expf(-(s / (float)a.Ci) * a.alpha);
-}
-// flow differences anchored at (y,x)
-__device__ __forceinline__ float diff_x(const SmoothArgs& a, const float* f, int y, int x) {
-  const float* r = f + (long)y * a.W + x;
-  return a.order == 1 ? (r[1] - r[0]) * a.fscale : ((r[2] - r[1]) - (r[1] - r[0])) * a.fscale;
-}
-__device__ __forceinline__ float diff_y(const SmoothArgs& a, const float* f, int y, int x) {
-  const float* r = f + (long)y * a.W + x;
-  const int W = a.W;
-  return a.order == 1 ? (r[W] - r[0]) * a.fscale : ((r[2 * W] - r[W]) - (r[W] - r[0])) * a.fscale;
-}
 
 // A workgroup covers 256 columns x `rows` rows (chosen at launch so that ~2000 workgroups remain): fewer
 // partial sums meet in the slotted rows (9216 workgroups x 2 atomics over 64 rows serialised ~290 deep at

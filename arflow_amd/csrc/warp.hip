@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "taps.hpp"
 #include "featnorm_stats.hpp"
+#include "smooth_dev.hpp"
 
 namespace {
 
@@ -1016,17 +1017,33 @@ __device__ __forceinline__ SplatTaps splat_taps(float cx, float cy, int H, int W
   return t;
 }
 
+// SM: the same launch also takes the edge-aware smoothness partial sums of its tile's pixels (smooth_fwd_kernel's
+// arithmetic, smooth_dev.hpp) -- UFlowLoss needs the range map AND the smoothness term of the same level-2 flows
+// (losses/uflow_loss.py:43,62-102): one launch instead of two at a size where a launch costs more than either.
+template <bool SM = false>
 __global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ flow, float* __restrict__ out,
-                                                    int nimg, int H, int W, long fbs, int variant) {
+                                                    int nimg, int H, int W, long fbs, int variant,
+                                                    SmoothArgs sa = SmoothArgs{}, float* __restrict__ sums = nullptr,
+                                                    int nrows = 0) {
   constexpr int WMAX = 128, HMAX = 64;
   constexpr float FIX = 4194304.f;  // 2^22
   __shared__ unsigned cellv[WMAX * HMAX];
   __shared__ int red[4][4];
   __shared__ int box[4];
+  __shared__ float sred[2 * 4];
   int btx, bty, b;
-  if (!af_tile_of_block((W + 31) / 32, (H + 7) / 8, nimg, btx, bty, b)) return;
+  if (!af_tile_of_block((W + 31) / 32, (H + 7) / 8, nimg, btx, bty, b)) {
+    if (SM && threadIdx.x == 0) af_store_partial(sums, nrows, 0.f, 0.f, 0.f);  // padding workgroup: its row must be defined
+    return;
+  }
   const int x = btx * 32 + (int)(threadIdx.x & 31), y = bty * 8 + (int)(threadIdx.x >> 5);
   const bool inside = x < W && y < H;
+  if (SM) {
+    float part[2] = {0.f, 0.f};
+    if (inside) smooth_pixel<3>(sa, sa.img + (long)b * 3 * H * W, sa.flow + (long)b * sa.fbs, y, x, part[0], part[1]);
+    af_block_sum<2>(part, sred);
+    if (threadIdx.x == 0) af_store_partial(sums, nrows, part[0], part[1], 0.f);
+  }
   SplatTaps t;
 #pragma unroll
   for (int k = 0; k < 4; ++k) t.ok[k] = false, t.xi[k] = t.yi[k] = 0, t.w[k] = 0.f;
@@ -1305,8 +1322,35 @@ extern "C" int arflow_splat_map(const float* flow, float* out, int B, int H, int
   hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * H * W, st);
   if (e != hipSuccess) return af_hip_status(e);
   const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
-  hipLaunchKernelGGL(splat_kernel, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, flow, out, B, H, W, flow_bstride,
+  hipLaunchKernelGGL(splat_kernel<false>, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, flow, out, B, H, W, flow_bstride,
                      variant);
+  return af_launch_status();
+}
+
+// compute_range_map(flow) (variant 0 of arflow_splat_map) AND the smoothness sums of arflow_smooth_fwd(flow, img, ...) in
+// ONE launch.  `out` must arrive ZERO-FILLED when prezeroed != 0 (arflow_down4_gray_z does it), else it is cleared here.
+extern "C" int arflow_splat_smooth_fwd(const float* flow, const float* img, float* out, float* sums, int B, int H, int W,
+                                       long flow_bstride, float flow_scale, float alpha, int order, int wmode, int penalty,
+                                       int prezeroed, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(img);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE_PTR(sums);
+  AF_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(order == 1 || order == 2, ARFLOW_EPARAM);
+  AF_REQUIRE(wmode == 0 || wmode == 1, ARFLOW_EPARAM);
+  AF_REQUIRE(penalty == 0 || penalty == 1, ARFLOW_EPARAM);
+  hipStream_t st = (hipStream_t)stream;
+  if (!prezeroed) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * H * W, st);
+    if (e != hipSuccess) return af_hip_status(e);
+  }
+  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+  const SmoothArgs sa{flow, img, 3, H, W, flow_bstride, flow_scale, alpha, order, wmode, penalty};
+  hipLaunchKernelGGL(splat_kernel<true>, dim3(af_grid_for_tiles(tiles)), dim3(256), 0, st, flow, out, B, H, W, flow_bstride,
+                     0, sa, sums, af_sums_rows(B, H, W));
   return af_launch_status();
 }
 

@@ -871,9 +871,10 @@ def census_warp_loss(gray_a, gray_b, flow, occ_small, patch_size=7):
     return CensusWarpLossFunction.apply(gray_a, gray_b, flow, occ_small, patch_size)
 
 
-def down4_gray(img, want_small=True):
+def down4_gray(img, want_small=True, zero_plane=False):
     """(downsample(img, x1/4) or None, rgb_to_grayscale(img) * 255) from ONE read of the image (no gradient: the
-    reference applies both to data only, losses/uflow_loss.py:59-60, utils/uflow_utils.py:248)."""
+    reference applies both to data only, losses/uflow_loss.py:59-60, utils/uflow_utils.py:248).  zero_plane=True also
+    returns a zero-filled [B,1,H/4,W/4] plane cleared by the same launch (the splat target of splat_smooth)."""
     _need_gpu(img)
     img = img.detach().contiguous()
     B, C, H, W = img.shape
@@ -881,9 +882,10 @@ def down4_gray(img, want_small=True):
         raise ValueError('down4_gray expects a [B,3,H,W] image')
     small = torch.empty(B, 3, H // 4, W // 4, device=img.device, dtype=torch.float32) if want_small else None
     gray = torch.empty(B, 1, H, W, device=img.device, dtype=torch.float32)
+    zero = torch.empty(B, 1, H // 4, W // 4, device=img.device, dtype=torch.float32) if zero_plane else None
     with torch.cuda.device_of(img):
-        _call('arflow_down4_gray', _p(img), _p(small), _p(gray), B, H, W, _stream(), key=(B, H, W))
-    return small, gray
+        _call('arflow_down4_gray_z', _p(img), _p(small), _p(gray), _p(zero), B, H, W, _stream(), key=(B, H, W))
+    return (small, gray, zero) if zero_plane else (small, gray)
 
 
 class TernaryDistFunction(torch.autograd.Function):
@@ -1051,6 +1053,47 @@ class SmoothSumsFunction(torch.autograd.Function):
 
 def smooth_sums(flow, img, flow_scale, alpha, order, wmode, penalty):
     return SmoothSumsFunction.apply(flow, img, flow_scale, alpha, order, wmode, penalty)
+
+
+class SplatSmoothFunction(torch.autograd.Function):
+    """(smoothness sums of SmoothSumsFunction, compute_range_map(flow)) from ONE launch (arflow_splat_smooth_fwd): UFlowLoss
+    takes both from the same level-2 flows.  ``range_out``: a ZERO-FILLED [B,1,H,W] plane (down4_gray(zero_plane=True)) or
+    None (cleared here).  The range map carries no gradient (the reference detaches it, losses/uflow_loss.py:43)."""
+
+    @staticmethod
+    def forward(ctx, flow, img, range_out, flow_scale, alpha, order, wmode, penalty):
+        _need_gpu(flow, img)
+        flow, fbs = _flow_view(flow)
+        img = img.contiguous()
+        B, _, H, W = flow.shape
+        if img.shape != (B, 3, H, W):
+            raise ValueError('splat_smooth expects a [B,3,H,W] image at the resolution of the flow')
+        pre = range_out is not None
+        if not pre:
+            range_out = torch.empty(B, 1, H, W, device=flow.device, dtype=torch.float32)
+        buf = _new_sums(flow.device, B, H, W)
+        args = (B, 3, H, W, fbs, float(flow_scale), float(alpha), int(order), int(wmode), int(penalty))
+        with torch.cuda.device_of(flow):
+            _call('arflow_splat_smooth_fwd', _p(flow), _p(img), _p(range_out), _p(buf), B, H, W, fbs, float(flow_scale),
+                  float(alpha), int(order), int(wmode), int(penalty), int(pre), _stream(), key=(B, 3, H, W))
+        ctx.save_for_backward(flow, img)
+        ctx.args = args
+        ctx.mark_non_differentiable(range_out)
+        return _fold_sums(buf, 2), range_out
+
+    @staticmethod
+    def backward(ctx, gsums, g_unused):
+        flow, img = ctx.saved_tensors
+        B, _, H, W = flow.shape
+        coef = gsums.contiguous()
+        g = torch.empty(B, 2, H, W, device=flow.device, dtype=torch.float32)
+        with torch.cuda.device_of(flow):
+            _call('arflow_smooth_bwd', _p(flow), _p(img), _p(coef), _p(g), *ctx.args, _stream(), key=(B, 3, H, W))
+        return g, None, None, None, None, None, None, None
+
+
+def splat_smooth(flow, img, range_out, flow_scale, alpha, order, wmode, penalty):
+    return SplatSmoothFunction.apply(flow, img, range_out, flow_scale, alpha, order, wmode, penalty)
 
 
 # ------------------------------------------------------------------------------------------------

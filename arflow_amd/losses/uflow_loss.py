@@ -63,20 +63,19 @@ class UFlowLoss(nn.Module):
     def _both_directions(self, output, target):
         """with_bk, as ONE pass over a batch of 2B samples s = 2 b + direction: [B,4,h,w] flows ARE [2B,2,h,w], the
         [B,6,H,W] pair IS [2B,3,H,W] (views, no copy); sample s reads its second image / its occlusion map from its
-        partner s ^ 1.  1 + 1 + 1 + 1 launches forward (grey + x1/4 copy, range maps, census, smoothness) and 1 + 1
+        partner s ^ 1.  3 launches forward (grey planes + x1/4 copies, range maps + smoothness sums, census) and 1 + 1
         backward for what the per-direction path issues twice; the smoothness term only needs the directions' sum."""
         cfg = self.cfg
         B, _, H, W = target.shape
         h, w = output[2].shape[2:]
-        small, gray = AF.down4_gray(target.view(2 * B, 3, H, W))
-        f0, f2 = output[0].view(2 * B, 2, H, W), output[2].view(2 * B, 2, h, w)
-        occ = AF.splat_map(f2, 0)
-        l_fw, l_bw, mask = AF.census_warp_pair_loss(gray, f0, occ, 7)
-        loss_warp = cfg.w_census * l_fw + cfg.w_census * l_bw
         order = int(cfg.smooth_order)
         if order not in (1, 2):
             raise NotImplementedError('smooth_order must be 1 or 2')
-        s = AF.smooth_sums(f2, small, 1.0, float(cfg.edge_constant), order, 1, 1)
+        small, gray, occ = AF.down4_gray(target.view(2 * B, 3, H, W), zero_plane=True)  # occ: cleared, the splat target
+        f0, f2 = output[0].view(2 * B, 2, H, W), output[2].view(2 * B, 2, h, w)
+        s, occ = AF.splat_smooth(f2, small, occ, 1.0, float(cfg.edge_constant), order, 1, 1)  # range maps + smoothness sums
+        l_fw, l_bw, mask = AF.census_warp_pair_loss(gray, f0, occ, 7)
+        loss_warp = cfg.w_census * l_fw + cfg.w_census * l_bw
         nx, ny = float(B * 2 * h * (w - order)), float(B * 2 * (h - order) * w)  # elements per DIRECTION
         loss_smooth = cfg.w_smooth * (s[0] / nx + s[1] / ny) / 2.
         return loss_warp + loss_smooth, loss_warp, loss_smooth, output[0].abs().mean(), mask.view(B, 2, 1, H, W)[:, 0]

@@ -141,7 +141,10 @@ def algorithmic_bytes(name, shape):
     if name in ('arflow_census_warp_bwd', 'arflow_census_warp_pair_bwd'):
         B, H, W = shape[:3]  # grey a, grey b, flow 2, dham 1 in; gflow 2 out
         return 4 * B * H * W * (1 + 1 + 2 + 1 + 2)
-    if name == 'arflow_down4_gray':
+    if name == 'arflow_splat_smooth_fwd':  # flow 2 + image 3 in, range map 1 out
+        B, Ci, H, W = shape
+        return 4 * B * H * W * (2 + Ci + 1)
+    if name in ('arflow_down4_gray', 'arflow_down4_gray_z'):
         B, H, W = shape  # image 3 in; grey 1 + 3/16 out
         return 4 * B * H * W * (3 + 1) + 4 * B * 3 * (H // 4) * (W // 4)
     if name == 'arflow_photo_fwd':

@@ -292,6 +292,17 @@ int arflow_census_warp_pair_bwd(const float* gray, const float* flow, long flow_
  * small[B,3,H/4,W/4] = downsample(im, x1/4) as arflow_down4 (losses/uflow_loss.py:59-60) from the same read.
  * im: [B,3,H,W], H % 4 == 0, W % 4 == 0. */
 int arflow_down4_gray(const float* im, float* small, float* gray, int B, int H, int W, arflow_stream_t stream);
+/* As arflow_down4_gray; additionally clears zero_plane ([B, H/4, W/4] floats, nullable): the accumulation target of the
+ * range-map splat that follows (arflow_splat_smooth_fwd with prezeroed = 1), saving its fill launch. */
+int arflow_down4_gray_z(const float* im, float* small, float* gray, float* zero_plane, int B, int H, int W,
+                        arflow_stream_t stream);
+/* compute_range_map(flow) (utils/uflow_utils.py:80-160; arflow_splat_map variant 0) AND the edge-aware smoothness sums of
+ * arflow_smooth_fwd(flow, img [B,3,H,W], ...) (losses/uflow_loss.py:62-102) in ONE launch: UFlowLoss needs both of the same
+ * level-2 flows.  out: [B,1,H,W] range map (prezeroed != 0: the caller guarantees it arrives zero-filled); sums as for
+ * arflow_smooth_fwd.  The smoothness backward is arflow_smooth_bwd. */
+int arflow_splat_smooth_fwd(const float* flow, const float* img, float* out, float* sums, int B, int H, int W,
+                            long flow_bstride, float flow_scale, float alpha, int order, int wmode, int penalty, int prezeroed,
+                            arflow_stream_t stream);
 
 
 /* ---- SSIM + L1 photometric term (losses/flow_loss.py:13-27, losses/loss_blocks.py:65-84) --------
