@@ -63,6 +63,7 @@ PROTOTYPES = {
     'arflow_census_warp_bwd': [c_fp, c_fp, c_fp, c_l, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'arflow_census_warp_pair_fwd': [c_fp, c_fp, c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'arflow_census_warp_pair_bwd': [c_fp, c_fp, c_l, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
+    'arflow_uflow_pair_bwd': [c_fp, c_fp, c_l, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_l, c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_fp],
     'arflow_down4_gray_z': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
     'arflow_splat_smooth_fwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_l, c_f, c_f, c_i, c_i, c_i, c_i, c_fp],
     'arflow_down4_gray': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],

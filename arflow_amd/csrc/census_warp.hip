@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "census_tile.hpp"
+#include "smooth_dev.hpp"
 #include "taps.hpp"
 
 namespace {
@@ -199,10 +200,10 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const float* __restrict__ gray_
 }
 
 template <int R>
-__global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ gray_a, const float* __restrict__ gray_b,
-                                                 const float* __restrict__ flow, long fbs,
-                                                 const float* __restrict__ dham, const float* __restrict__ scale,
-                                                 float* __restrict__ gflow, int nimg, int H, int W, int pair) {
+__device__ __forceinline__ void bwd_body(const float* __restrict__ gray_a, const float* __restrict__ gray_b,
+                                         const float* __restrict__ flow, long fbs,
+                                         const float* __restrict__ dham, const float* __restrict__ scale,
+                                         float* __restrict__ gflow, int nimg, int H, int W, int pair) {
   __shared__ __attribute__((aligned(16))) float ga[ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float gb[ROWS * PITCH];
   __shared__ __attribute__((aligned(16))) float gg[ROWS * PITCH];
@@ -278,6 +279,34 @@ __global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ gray_
       make_float4(sc * acc[0] * cdx[0], sc * acc[1] * cdx[1], sc * acc[2] * cdx[2], sc * acc[3] * cdx[3]);
   *reinterpret_cast<float4*>(gf + cs) =
       make_float4(sc * acc[0] * cdy[0], sc * acc[1] * cdy[1], sc * acc[2] * cdy[2], sc * acc[3] * cdy[3]);
+}
+
+template <int R>
+__global__ __launch_bounds__(NT) void bwd_kernel(const float* __restrict__ gray_a, const float* __restrict__ gray_b,
+                                                 const float* __restrict__ flow, long fbs,
+                                                 const float* __restrict__ dham, const float* __restrict__ scale,
+                                                 float* __restrict__ gflow, int nimg, int H, int W, int pair) {
+  bwd_body<R>(gray_a, gray_b, flow, fbs, dham, scale, gflow, nimg, H, W, pair);
+}
+
+// The WHOLE backward of UFlowLoss as one launch: workgroups [0, census_blocks) run the census + warp backward of both
+// directions (bwd_body, pair form), the rest the smoothness backward of the level-2 flows (smooth_bwd_pixel: one row of
+// 256 columns per workgroup) -- two independent kernels that used to pay two launch latencies back to back.
+template <int R>
+__global__ __launch_bounds__(NT) void pair_bwd_smooth_kernel(const float* __restrict__ gray, const float* __restrict__ flow,
+                                                             long fbs, const float* __restrict__ dham,
+                                                             const float* __restrict__ scale2, float* __restrict__ gflow,
+                                                             int nimg, int H, int W, unsigned census_blocks, SmoothArgs sa,
+                                                             const float* __restrict__ coef, float* __restrict__ gflow2) {
+  if (blockIdx.x < census_blocks) {
+    bwd_body<R>(gray, gray, flow, fbs, dham, scale2, gflow, nimg, H, W, 1);
+    return;
+  }
+  const unsigned i = blockIdx.x - census_blocks;  // (b, y, x-block) of the level-2 grid
+  const unsigned nxb = (unsigned)((sa.W + 255) / 256);
+  const int xb = (int)(i % nxb), y = (int)((i / nxb) % (unsigned)sa.H), b = (int)(i / (nxb * (unsigned)sa.H));
+  const int x = xb * 256 + (int)threadIdx.x;
+  if (b < nimg && x < sa.W) smooth_bwd_pixel<3>(sa, coef, gflow2, b, y, x);
 }
 
 // grey plane (x255) of an RGB image and, optionally, its bilinear x1/4 copy (align_corners=False on a multiple-of-4
@@ -426,4 +455,39 @@ extern "C" int arflow_census_warp_pair_bwd(const float* gray, const float* flow,
   AF_REQUIRE(B2 % 2 == 0, ARFLOW_ESHAPE);
   AF_REQUIRE_PTR(scale2);
   return census_warp_bwd_impl(gray, gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, radius, stream, 1);
+}
+
+// Backward of BOTH loss terms of UFlowLoss in one launch: arflow_census_warp_pair_bwd + arflow_smooth_bwd (3-channel image,
+// level-2 flows [B2,2,h2,w2] with batch stride flow2_bstride); coef2 = the two smoothness-sum gradients.
+extern "C" int arflow_uflow_pair_bwd(const float* gray, const float* flow, long flow_bstride, const float* dham,
+                                     const float* scale2, float* gflow, int B2, int H, int W, int radius, const float* flow2,
+                                     long flow2_bstride, const float* img2, const float* coef2, float* gflow2, int h2, int w2,
+                                     float flow_scale, float alpha, int order, int wmode, int penalty,
+                                     arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gray);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(dham);
+  AF_REQUIRE_PTR(scale2);
+  AF_REQUIRE_PTR(gflow);
+  AF_REQUIRE_PTR(flow2);
+  AF_REQUIRE_PTR(img2);
+  AF_REQUIRE_PTR(coef2);
+  AF_REQUIRE_PTR(gflow2);
+  AF_REQUIRE(B2 > 0 && B2 % 2 == 0 && H > 0 && W > 0 && B2 <= 65535 && H <= 8 * 65535 && h2 > 0 && w2 > 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(arflow_census_warp_supported(H, W), ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W && flow2_bstride >= 2L * h2 * w2, ARFLOW_ESHAPE);
+  AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
+  AF_REQUIRE((order == 1 || order == 2) && (wmode == 0 || wmode == 1) && (penalty == 0 || penalty == 1), ARFLOW_EPARAM);
+  namespace cw = census_warp;
+  const unsigned cb = af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B2);
+  const unsigned sb = (unsigned)af_cdiv(w2, 256) * (unsigned)h2 * (unsigned)B2;
+  const SmoothArgs sa{flow2, img2, 3, h2, w2, flow2_bstride, flow_scale, alpha, order, wmode, penalty};
+  hipStream_t st = (hipStream_t)stream;
+  switch (radius) {
+    case 1: hipLaunchKernelGGL(cw::pair_bwd_smooth_kernel<1>, dim3(cb + sb), dim3(cw::NT), 0, st, gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, cb, sa, coef2, gflow2); break;
+    case 2: hipLaunchKernelGGL(cw::pair_bwd_smooth_kernel<2>, dim3(cb + sb), dim3(cw::NT), 0, st, gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, cb, sa, coef2, gflow2); break;
+    default: hipLaunchKernelGGL(cw::pair_bwd_smooth_kernel<3>, dim3(cb + sb), dim3(cw::NT), 0, st, gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, cb, sa, coef2, gflow2); break;
+  }
+  return af_launch_status();
 }

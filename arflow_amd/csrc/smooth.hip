@@ -49,34 +49,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(SmoothArgs a, const flo
                                                         float* __restrict__ gflow) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
   if (x >= a.W) return;
-  const int o = a.order;
-  const float* ib = a.img + (long)b * a.Ci * a.H * a.W;
-  const float* fb = a.flow + (long)b * a.fbs;
-  const long cs = (long)a.H * a.W;
-  const float cx = coef[0] * a.fscale, cy = coef[1] * a.fscale;
-  float g[2] = {0.f, 0.f};
-  // pixel (y,x) enters the difference anchored at x-k with stencil coefficient st[k]
-  // order 1: {-1, +1}; order 2: {+1, -2, +1}
-  const float st1[2] = {-1.f, 1.f};
-  const float st2[3] = {1.f, -2.f, 1.f};
-  for (int k = 0; k <= o; ++k) {
-    const float s = o == 1 ? st1[k] : st2[k];
-    const int xa = x - k;
-    if (xa >= 0 && xa < a.W - o) {
-      const float w = edge_wx<CI>(a, ib, y, xa) * s * cx;
-      g[0] = fmaf(w, dpen(diff_x(a, fb, y, xa), a.penalty), g[0]);
-      g[1] = fmaf(w, dpen(diff_x(a, fb + cs, y, xa), a.penalty), g[1]);
-    }
-    const int ya = y - k;
-    if (ya >= 0 && ya < a.H - o) {
-      const float w = edge_wy<CI>(a, ib, ya, x) * s * cy;
-      g[0] = fmaf(w, dpen(diff_y(a, fb, ya, x), a.penalty), g[0]);
-      g[1] = fmaf(w, dpen(diff_y(a, fb + cs, ya, x), a.penalty), g[1]);
-    }
-  }
-  float* go = gflow + (long)b * 2 * cs + (long)y * a.W + x;
-  go[0] = g[0];
-  go[cs] = g[1];
+  smooth_bwd_pixel<CI>(a, coef, gflow, b, y, x);
 }
 
 // bilinear x1/4, align_corners=False on a multiple-of-4 grid: source coordinate of output i is

@@ -863,6 +863,63 @@ def census_warp_pair_loss(gray2, flow2, occ_small2, patch_size=7):
     return CensusWarpPairLossFunction.apply(gray2, flow2, occ_small2, patch_size)
 
 
+class UFlowPairLossFunction(torch.autograd.Function):
+    """Both loss terms of UFlowLoss for both directions (losses/uflow_loss.py:30-102) behind ONE autograd node: forward =
+    arflow_splat_smooth_fwd (range maps + smoothness sums of the level-2 flows) + arflow_census_warp_pair_fwd; backward = ONE
+    launch (arflow_uflow_pair_bwd: census + warp backward and smoothness backward as workgroup roles).  Batch layout as
+    CensusWarpPairLossFunction (sample s = 2 b + direction).  Returns (census loss fw, census loss bw, smoothness sums [2],
+    mask [2B,1,H,W]); gradients w.r.t. the level-0 and level-2 flows."""
+
+    @staticmethod
+    def forward(ctx, gray2, small2, flow0, flow2, occ_zeroed, alpha, order, patch_size):
+        _need_gpu(gray2, small2, flow0, flow2)
+        gray2, small2 = gray2.detach().contiguous(), small2.detach().contiguous()
+        flow0, fbs0 = _flow_view(flow0)
+        flow2, fbs2 = _flow_view(flow2)
+        B2, _, H, W = gray2.shape
+        h, w = flow2.shape[2:]
+        if B2 % 2 or flow0.shape != (B2, 2, H, W) or (h, w) != (H // 4, W // 4) or small2.shape != (B2, 3, h, w):
+            raise ValueError('uflow_pair_loss: inconsistent shapes')
+        r = int(patch_size) // 2
+        pre = occ_zeroed is not None
+        occ = occ_zeroed if pre else torch.empty(B2, 1, h, w, device=gray2.device, dtype=torch.float32)
+        sbuf = _new_sums(gray2.device, B2, h, w)
+        cbuf = _new_sums(gray2.device, B2, H, W)
+        dham = torch.empty(B2, 1, H, W, device=gray2.device, dtype=torch.float32)
+        mask = torch.empty(B2, 1, H, W, device=gray2.device, dtype=torch.float32)
+        with torch.cuda.device_of(gray2):
+            _call('arflow_splat_smooth_fwd', _p(flow2), _p(small2), _p(occ), _p(sbuf), B2, h, w, fbs2, 1.0, float(alpha),
+                  int(order), 1, 1, int(pre), _stream(), key=(B2, 3, h, w))
+            _call('arflow_census_warp_pair_fwd', _p(gray2), _p(flow0), fbs0, _p(occ), _p(mask), _p(dham), _p(cbuf), B2, H, W, r,
+                  _stream(), key=(B2, H, W))
+        sums = _fold_sums(cbuf, 4)
+        den = torch.stack([_ddp.global_denominator(sums[1]), _ddp.global_denominator(sums[3])]) + 1e-6 / _ddp.world_size()
+        inv = 1.0 / den
+        ctx.save_for_backward(gray2, small2, flow0, flow2, dham, inv)
+        ctx.cfg = (r, fbs0, fbs2, float(alpha), int(order))
+        ctx.mark_non_differentiable(mask)
+        return sums[0] * inv[0], sums[2] * inv[1], _fold_sums(sbuf, 2), mask
+
+    @staticmethod
+    def backward(ctx, g0, g1, gs, gmask_unused):
+        gray2, small2, flow0, flow2, dham, inv = ctx.saved_tensors
+        r, fbs0, fbs2, alpha, order = ctx.cfg
+        B2, _, H, W = gray2.shape
+        h, w = flow2.shape[2:]
+        scale = (torch.stack([g0.reshape(()), g1.reshape(())]) * inv).contiguous()
+        coef = gs.contiguous()
+        gf0 = torch.empty(B2, 2, H, W, device=gray2.device, dtype=torch.float32)
+        gf2 = torch.empty(B2, 2, h, w, device=gray2.device, dtype=torch.float32)
+        with torch.cuda.device_of(gray2):
+            _call('arflow_uflow_pair_bwd', _p(gray2), _p(flow0), fbs0, _p(dham), _p(scale), _p(gf0), B2, H, W, r, _p(flow2),
+                  fbs2, _p(small2), _p(coef), _p(gf2), h, w, 1.0, alpha, order, 1, 1, _stream(), key=(B2, H, W))
+        return None, None, gf0, gf2, None, None, None, None
+
+
+def uflow_pair_loss(gray2, small2, flow0, flow2, occ_zeroed, alpha, order, patch_size=7):
+    return UFlowPairLossFunction.apply(gray2, small2, flow0, flow2, occ_zeroed, alpha, order, patch_size)
+
+
 def census_warp_supported(H, W):
     return bool(_lib.load().arflow_census_warp_supported(int(H), int(W)))
 

@@ -63,7 +63,7 @@ class UFlowLoss(nn.Module):
     def _both_directions(self, output, target):
         """with_bk, as ONE pass over a batch of 2B samples s = 2 b + direction: [B,4,h,w] flows ARE [2B,2,h,w], the
         [B,6,H,W] pair IS [2B,3,H,W] (views, no copy); sample s reads its second image / its occlusion map from its
-        partner s ^ 1.  3 launches forward (grey planes + x1/4 copies, range maps + smoothness sums, census) and 1 + 1
+        partner s ^ 1.  3 launches forward (grey planes + x1/4 copies, range maps + smoothness sums, census) and ONE
         backward for what the per-direction path issues twice; the smoothness term only needs the directions' sum."""
         cfg = self.cfg
         B, _, H, W = target.shape
@@ -73,8 +73,8 @@ class UFlowLoss(nn.Module):
             raise NotImplementedError('smooth_order must be 1 or 2')
         small, gray, occ = AF.down4_gray(target.view(2 * B, 3, H, W), zero_plane=True)  # occ: cleared, the splat target
         f0, f2 = output[0].view(2 * B, 2, H, W), output[2].view(2 * B, 2, h, w)
-        s, occ = AF.splat_smooth(f2, small, occ, 1.0, float(cfg.edge_constant), order, 1, 1)  # range maps + smoothness sums
-        l_fw, l_bw, mask = AF.census_warp_pair_loss(gray, f0, occ, 7)
+        # range maps + smoothness sums, then census of both directions; ONE launch backward for all of it
+        l_fw, l_bw, s, mask = AF.uflow_pair_loss(gray, small, f0, f2, occ, float(cfg.edge_constant), order, 7)
         loss_warp = cfg.w_census * l_fw + cfg.w_census * l_bw
         nx, ny = float(B * 2 * h * (w - order)), float(B * 2 * (h - order) * w)  # elements per DIRECTION
         loss_smooth = cfg.w_smooth * (s[0] / nx + s[1] / ny) / 2.

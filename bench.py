@@ -138,7 +138,7 @@ def algorithmic_bytes(name, shape):
     if name in ('arflow_census_warp_fwd', 'arflow_census_warp_pair_fwd'):
         B, H, W = shape[:3]  # grey a, grey b, flow 2, range map 1/16 in; mask 1, dham 1 out
         return 4 * B * H * W * (1 + 1 + 2 + 1 + 1) + 4 * B * (H // 4) * (W // 4)
-    if name in ('arflow_census_warp_bwd', 'arflow_census_warp_pair_bwd'):
+    if name in ('arflow_census_warp_bwd', 'arflow_census_warp_pair_bwd', 'arflow_uflow_pair_bwd'):
         B, H, W = shape[:3]  # grey a, grey b, flow 2, dham 1 in; gflow 2 out
         return 4 * B * H * W * (1 + 1 + 2 + 1 + 2)
     if name == 'arflow_splat_smooth_fwd':  # flow 2 + image 3 in, range map 1 out
@@ -189,7 +189,7 @@ def valu_slots(name, shape, trans_slots=None):
     if name in ('arflow_census_fwd', 'arflow_census_warp_fwd', 'arflow_census_warp_pair_fwd'):
         B, H, W = shape[:3]  # 49 neighbours x (2 sub, 2 fma, 2 rsq, mul, fma, mul, add, rcp, fma) per image pair
         return B * H * W * 49 * (10 + 3 * T)
-    if name in ('arflow_census_bwd', 'arflow_census_warp_bwd', 'arflow_census_warp_pair_bwd'):
+    if name in ('arflow_census_bwd', 'arflow_census_warp_bwd', 'arflow_census_warp_pair_bwd', 'arflow_uflow_pair_bwd'):
         B, H, W = shape[:3]  # 48 neighbours x (2 sub, 2 fma, 2 rsq, mul, fma, fma, rcp, 5 mul, add, fma)
         return B * H * W * 48 * (14 + 3 * T)
     if name == 'arflow_photo_fwd':

@@ -288,6 +288,13 @@ int arflow_census_warp_pair_fwd(const float* gray, const float* flow, long flow_
                                 arflow_stream_t stream);
 int arflow_census_warp_pair_bwd(const float* gray, const float* flow, long flow_bstride, const float* dham,
                                 const float* scale2, float* gflow, int B2, int H, int W, int radius, arflow_stream_t stream);
+/* The whole backward of UFlowLoss as ONE launch: arflow_census_warp_pair_bwd (-> gflow [B2,2,H,W]) and arflow_smooth_bwd of
+ * the level-2 flows flow2 [B2,2,h2,w2] with the x1/4 images img2 [B2,3,h2,w2] and the two sum gradients coef2
+ * (-> gflow2 [B2,2,h2,w2]) as workgroup roles of one kernel. */
+int arflow_uflow_pair_bwd(const float* gray, const float* flow, long flow_bstride, const float* dham, const float* scale2,
+                          float* gflow, int B2, int H, int W, int radius, const float* flow2, long flow2_bstride,
+                          const float* img2, const float* coef2, float* gflow2, int h2, int w2, float flow_scale, float alpha,
+                          int order, int wmode, int penalty, arflow_stream_t stream);
 /* gray[B,1,H,W] = rgb_to_grayscale(im) * 255 (utils/uflow_utils.py:227-231) and, if small != NULL,
  * small[B,3,H/4,W/4] = downsample(im, x1/4) as arflow_down4 (losses/uflow_loss.py:59-60) from the same read.
  * im: [B,3,H,W], H % 4 == 0, W % 4 == 0. */
