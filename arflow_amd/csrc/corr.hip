@@ -410,9 +410,9 @@ int af_level_corr_fwd_launch(const float* x1, const float* x2w, const double* ac
 int af_level_corr_bwd_launch(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
                              long x1n_bstride, const float* x2w, const float* stats, float* gx1n, float* gx2n, int B, int C,
                              int H, int W, float negative_slope, hipStream_t st, float* zero_c, float* zero_f,
-                             float* zero_fc) {
+                             float* zero_fc, int* zero_i) {
   return corr_v2::launch_bwd(gout, nullptr, negative_slope == 1.0f ? nullptr : sign_bits, negative_slope, x1n, x2w, gx1n,
-                             gx2n, B, C, H, W, st, gout_bstride, 0, x1n_bstride, stats, zero_c, zero_f, zero_fc);
+                             gx2n, B, C, H, W, st, gout_bstride, 0, x1n_bstride, stats, zero_c, zero_f, zero_fc, zero_i);
 }
 extern "C" int arflow_level_supported(int C, int W, int max_disp) { return corr_v2::eligible(C, W, max_disp) ? 1 : 0; }
 
@@ -457,7 +457,7 @@ extern "C" int arflow_level_corr_bwd(const float* gout, long gout_bstride, const
   AF_REQUIRE(gout_bstride >= vol && gout_bstride % 4 == 0, ARFLOW_ESHAPE);
   AF_REQUIRE(x1n_bstride >= (long)C * H * W && x1n_bstride % 4 == 0, ARFLOW_ESHAPE);
   return af_level_corr_bwd_launch(gout, gout_bstride, sign_bits, x1n, x1n_bstride, x2w, stats, gx1n, gx2n, B, C, H, W,
-                                  negative_slope, (hipStream_t)stream, nullptr, nullptr, nullptr);
+                                  negative_slope, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 static int corr_bwd_impl(const float* gout, long gout_bstride, const float* out, long out_bstride,

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
                                                     long gbs /* batch stride of gout */, long fbs /* of fout */,
                                                     long x1bs /* batch stride of x1 */, const float* __restrict__ stats,
                                                     float* __restrict__ zero_c, float* __restrict__ zero_f,
-                                                    float* __restrict__ zero_fc) {
+                                                    float* __restrict__ zero_fc, int* __restrict__ zero_i) {
   // zero_c [B,C,H,W], zero_f [B,2,H,W], zero_fc [B,2,H/2,W/2] (level backward, each nullable): accumulation targets of the
   // warp backward that follows, zero-filled HERE -- mode-1 workgroups clear their tile of zero_c next to the gradient
   // they store, split-0 mode-0 workgroups their tile of the two flow-gradient buffers -- instead of by fill launches
@@ -531,6 +531,7 @@ __global__ __launch_bounds__(NT, 3) void bwd_kernel(const float* __restrict__ go
   float own[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // this wave's partials of the channels it owns
   const bool lane_in = gy < H && gx < W;
   if constexpr (NORM) {
+    if (zero_i && mode == 0 && split == 0 && btx == 0 && bty == 0 && threadIdx.x == 0) zero_i[b] = 0;  // per-sample flag word
     if (mode == 0 && split == 0 && wave == 0 && lane_in) {
       if (zero_f) {
         float* z = zero_f + (long)b * 2 * cs + (long)gy * W + gx;
@@ -647,7 +648,7 @@ inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign
                       const float* x2,
                       float* gx1, float* gx2, int B, int C, int H, int W, hipStream_t st, long gbs = 0, long fbs = 0,
                       long x1bs = 0, const float* stats = nullptr, float* zero_c = nullptr, float* zero_f = nullptr,
-                      float* zero_fc = nullptr) {
+                      float* zero_fc = nullptr, int* zero_i = nullptr) {
   if (gbs == 0) gbs = (long)N * N * H * W;
   if (fbs == 0) fbs = (long)N * N * H * W;
   if (x1bs == 0) x1bs = (long)C * H * W;
@@ -662,7 +663,7 @@ inline int launch_bwd(const float* gout, const float* fout, const unsigned* sign
   const int mb = gx1 ? 0 : 1;
 #define CORR_V2_BWD(NB, ACT, NN)                                                                                      \
   hipLaunchKernelGGL((bwd_kernel<NB, ACT, NN>), grid, dim3(NT), 0, st, gout, fout, sign_bits, slope, x1, x2, gx1, gx2, \
-                     B, C, H, W, inv_c, mb, nmodes, gbs, fbs, x1bs, stats, zero_c, zero_f, zero_fc)
+                     B, C, H, W, inv_c, mb, nmodes, gbs, fbs, x1bs, stats, zero_c, zero_f, zero_fc, zero_i)
   if (stats) {  // level kernels: always with the sign words of the fused LeakyReLU (ACT 2) or without activation (0)
     if (act == 1) return ARFLOW_EPARAM;
     if (tiles >= 768) {

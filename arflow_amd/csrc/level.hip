@@ -11,13 +11,17 @@
 //            -> warp backward (the concatenation's / residual's gradients of the flow added on the way out)
 //            -> adjoint of the x2 upsample.
 // The reference runs ~25 ATen kernels forward and ~60 backward per level for this.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "level_internal.hpp"
 
 namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr int SLAB_CAP = 768;  // cells per tile slab: windows up to e.g. 16 x 48 (a smooth flow gives ~10 x 36)
 struct BwdWs {
-  size_t g1, g2, gfl, acc, total;
+  size_t g1, g2, gfl, acc, slab, meta, ovf, total;
+  int slab_cap;
 };
 inline BwdWs bwd_layout(int B, int C, int H, int W) {
   BwdWs w;
@@ -26,7 +30,17 @@ inline BwdWs bwd_layout(int B, int C, int H, int W) {
   w.g2 = n;
   w.gfl = 2 * n;
   w.acc = w.gfl + align256(sizeof(float) * (size_t)B * 2 * H * W);
-  w.total = w.acc + align256(sizeof(double) * (size_t)ARFLOW_FEATNORM_ACC_DOUBLES(B));
+  w.slab = w.acc + align256(sizeof(double) * (size_t)ARFLOW_FEATNORM_ACC_DOUBLES(B));
+  // two-pass source gradient of the warp at the fine level: one slab of SLAB_CAP cells per tile and channel
+  const size_t tiles = (size_t)((W + 31) / 32) * ((H + 7) / 8) * B;
+  static const bool slab_on = [] {
+    const char* e = getenv("ARFLOW_WARP_SLAB");
+    return e && e[0] == '1';
+  }();
+  w.slab_cap = (slab_on && tiles >= 768 && tiles / B <= 1024) ? SLAB_CAP : 0;
+  w.meta = w.slab + align256(sizeof(float) * tiles * C * (size_t)w.slab_cap);
+  w.ovf = w.meta + align256(16 * tiles);
+  w.total = w.ovf + align256(sizeof(int) * (size_t)B);
   return w;
 }
 }  // namespace
@@ -120,6 +134,8 @@ extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsi
   float* g2 = (float*)(base + ws.g2);
   float* gfl = (float*)(base + ws.gfl);
   double* acc = (double*)(base + ws.acc);
+  float* slab = ws.slab_cap ? (float*)(base + ws.slab) : nullptr;
+  int* ovf = (int*)(base + ws.ovf);
   const bool has_flow = flow_full != nullptr;
   if (has_flow) {
     AF_REQUIRE_PTR(x2w);
@@ -136,7 +152,8 @@ extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsi
   const bool up_atomic = false;
   int rc = af_level_corr_bwd_launch(gout, gout_bstride, sign_bits, x1n, x1n_bstride, second, stats, g1, g2, B, C, H, W,
                                     negative_slope, st, has_flow ? gx2 : nullptr,
-                                    has_flow ? (flow_is_coarse ? gfl : gflow) : nullptr, up_atomic ? gflow : nullptr);
+                                    has_flow ? (flow_is_coarse ? gfl : gflow) : nullptr, up_atomic ? gflow : nullptr,
+                                    slab ? ovf : nullptr);
   if (rc != ARFLOW_OK) return rc;
   if (!has_flow)  // the normalisation's backward (the concatenation's gradient of x1n added on load): its outputs ARE the results
     return af_featnorm_bwd_launch(g1, gx1n_direct, gx1n_direct_bstride, g2, x1, x2, stats, acc, gx1, gx2, B, (long)C * H * W,
@@ -148,7 +165,8 @@ extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsi
   if (rc != ARFLOW_OK) return rc;
   rc = af_level_warp_bwd_launch(g2, x2, x2w, flow_full, flow_bstride, gx2, flow_is_coarse ? gfl : gflow, B, C, H, W, pad_mode,
                                 align_corners, coord_norm, acc, nrows, stats, norm_mode, g1, gx1n_direct, gx1n_direct_bstride,
-                                x1, gx1, gflow_a, gflow_a_bstride, gflow_b, up_atomic ? gflow : nullptr, up_align_corners, st);
+                                x1, gx1, gflow_a, gflow_a_bstride, gflow_b, up_atomic ? gflow : nullptr, up_align_corners, slab,
+                                base + ws.meta, ovf, ws.slab_cap, st);
   if (rc != ARFLOW_OK || !flow_is_coarse || up_atomic) return rc;
   return af_up2_bwd_launch(gfl, gflow, B * 2, H, W, up_align_corners, st);
 }

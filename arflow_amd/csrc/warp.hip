@@ -756,14 +756,27 @@ static_assert(CCH == 4, "gt holds one float4 per pixel");
 
 // NB (level backward): gout is the gradient of the NORMALISED warped map; the normalisation's backward is applied while
 // the gradients are staged (flow_grad::norm_bwd_apply with x = the saved warped map `x2w`), see level_warp_bwd_flow_kernel.
-template <bool NB>
+// SLAB (level backward, two-pass form): instead of adding its window sums into gsrc with float atomics (~0.7 TB/s of added
+// bytes for these ragged 10 x 34 windows, tools/ubench/atomic_shape.hip; plain stores of the same shape run 4x faster) the
+// tile STORES them, dense, into its own slab -- slab[(tile * C + c) * cap + r * wq + cx], wq = the window width rounded up to
+// 4 -- with the window rectangle in meta[tile]; slab_gather_kernel then sums, per 8 x 32 block of gsrc, the slabs whose
+// rectangles meet it, in tile order.  A window that does not fit `cap` cells falls back to the atomics (gsrc arrives
+// zero-filled) and raises ovf[b], which makes the gather ADD to gsrc for that sample instead of overwriting it.
+struct SlabArgs {
+  float* base;
+  int4* meta;
+  int* ovf;
+  int cap;
+};
+
+template <bool NB, bool SLAB = false>
 __device__ __forceinline__ void warp_bwd_src_body(const float* __restrict__ gout,
                                                   const float* __restrict__ flow, float* __restrict__ gsrc,
                                                   int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
                                                   int pad, int align, int norm,
                                                   const float* __restrict__ x2w,
                                                   const double* __restrict__ rows, int nrows,
-                                                  const float* __restrict__ stats, int mode) {
+                                                  const float* __restrict__ stats, int mode, SlabArgs sl = SlabArgs{}) {
   // cell c lives at halfword cell_ptr[c + (c >> 5)]: the scan walks a lane-private run of consecutive cells,
   // and the +1-per-32 skew keeps 64 lanes with a stride that is a multiple of 32 off a common bank.
   // 16-bit cells (a workgroup has at most 4 * 256 = 1024 list entries) halve the array: 17 KB instead of
@@ -793,8 +806,15 @@ __device__ __forceinline__ void warp_bwd_src_body(const float* __restrict__ gout
   const int bx0 = bb.x0, by0 = bb.y0;
   const int bw = bb.x1 - bx0 + 1, bh = bb.y1 - by0 + 1;
   const bool empty = bb.x1 < bx0;
-  if (empty) return;  // no pixel of the tile samples inside the source: nothing to add (uniform)
+  const int wq = (bw + 3) & ~3;  // SLAB: row pitch of the tile's slab
   const bool priv = bw <= WMAX && bh <= HMAX;
+  const bool fits = SLAB && !empty && priv && bh * wq <= sl.cap;
+  const long tile_g = ((long)b * ((H + TY - 1) / TY) + bty) * ((W + TX - 1) / TX) + btx;
+  if (SLAB && blockIdx.y == 0 && threadIdx.x == 0) {
+    sl.meta[tile_g] = empty ? make_int4(0, 0, 0, 0) : (fits ? make_int4(bx0, by0, bw, bh) : make_int4(0, 0, -1, 0));
+    if (!empty && !fits) atomicOr(sl.ovf + b, 1);
+  }
+  if (empty) return;  // no pixel of the tile samples inside the source: nothing to add (uniform)
 
   const float wgt[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
   const bool ok[4] = {t.vx0 && t.vy0, t.vx1 && t.vy0, t.vx0 && t.vy1, t.vx1 && t.vy1};
@@ -909,6 +929,39 @@ __device__ __forceinline__ void warp_bwd_src_body(const float* __restrict__ gout
     gt[buf][threadIdx.x] = make_float4(nv[0], nv[1], nv[2], nv[3]);
     fetch(c0 + gridDim.y * CCH, nv);
     __syncthreads();
+    if (SLAB && fits) {  // dense sweep of the window: every cell (zeros included) into the tile's slab, plain stores
+      float* sb = sl.base + (tile_g * C + c0) * (long)sl.cap;
+      for (int i = threadIdx.x; i < bh * wq; i += NT) {
+        const int r = i / wq, cx = i - r * wq;
+        float acc[CCH] = {0.f, 0.f, 0.f, 0.f};
+        if (cx < bw) {
+          const int ci = r * wp + cx;
+          const int end = cell_ptr[slot_of(ci)], beg = ci > 0 ? cell_ptr[slot_of(ci - 1)] : 0;  // fill pointers: ends
+          for (int e = beg; e < end; e += 4) {
+            float2 en[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              en[u] = entry[min(e + u, end - 1)];
+              if (e + u >= end) en[u].y = 0.f;
+            }
+            float4 gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gv[u] = gt[buf][__float_as_int(en[u].x)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              acc[0] = fmaf(gv[u].x, en[u].y, acc[0]);
+              acc[1] = fmaf(gv[u].y, en[u].y, acc[1]);
+              acc[2] = fmaf(gv[u].z, en[u].y, acc[2]);
+              acc[3] = fmaf(gv[u].w, en[u].y, acc[3]);
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CCH; ++c)
+          if (c0 + c < C) sb[(long)c * sl.cap + i] = acc[c];
+      }
+      continue;
+    }
     for (int i = threadIdx.x; i < totalz; i += NT) {
       const int ci = ne_cell[i];
       const int beg = ne_beg[i], end = ne_beg[i + 1];
@@ -945,15 +998,81 @@ __device__ __forceinline__ void warp_bwd_src_body(const float* __restrict__ gout
     // reads before this buffer is overwritten two chunks later
   }
 }
-template <bool NB = false>
+template <bool NB = false, bool SLAB = false>
 __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restrict__ gout,
                                                           const float* __restrict__ flow, float* __restrict__ gsrc,
                                                           int nimg, int C, int Hs, int Ws, int H, int W, long fbs,
                                                           int pad, int align, int norm,
                                                           const float* __restrict__ x2w = nullptr,
                                                           const double* __restrict__ rows = nullptr, int nrows = 0,
-                                                          const float* __restrict__ stats = nullptr, int mode = 0) {
-  warp_bwd_src_body<NB>(gout, flow, gsrc, nimg, C, Hs, Ws, H, W, fbs, pad, align, norm, x2w, rows, nrows, stats, mode);
+                                                          const float* __restrict__ stats = nullptr, int mode = 0,
+                                                          SlabArgs sl = SlabArgs{}) {
+  warp_bwd_src_body<NB, SLAB>(gout, flow, gsrc, nimg, C, Hs, Ws, H, W, fbs, pad, align, norm, x2w, rows, nrows, stats, mode, sl);
+}
+
+// Second pass of the SLAB form: one workgroup per 8 x 32 block of gsrc (x a channel split): the rectangles of the sample's
+// T tiles are scanned (meta in LDS), and every pixel sums, in TILE ORDER, the slab cells of the tiles whose window
+// contains it -- plain loads, one plain store per pixel and channel; no atomics, no zero-fill of gsrc needed.
+constexpr int MAXT = 1024;
+__global__ __launch_bounds__(NT) void slab_gather_kernel(const float* __restrict__ slab, const int4* __restrict__ meta,
+                                                         const int* __restrict__ ovf, float* __restrict__ gsrc, int nimg,
+                                                         int C, int Hs, int Ws, int T, int cap) {
+  __shared__ int4 m[MAXT];
+  __shared__ unsigned char hit[MAXT];
+  __shared__ unsigned short list[MAXT];
+  __shared__ int nhit;
+  int bx, by, b;
+  if (!af_tile_of_block((Ws + TX - 1) / TX, (Hs + TY - 1) / TY, nimg, bx, by, b)) return;
+  const int sx0 = bx * TX, sy0 = by * TY;
+  for (int t = threadIdx.x; t < T; t += NT) {
+    const int4 mt = meta[(long)b * T + t];
+    m[t] = mt;
+    hit[t] = mt.z > 0 && mt.x < sx0 + TX && mt.x + mt.z > sx0 && mt.y < sy0 + TY && mt.y + mt.w > sy0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // the tiles whose window meets this block, compacted in TILE ORDER
+    int n = 0;
+    for (int t = 0; t < T; ++t)
+      if (hit[t]) list[n++] = (unsigned short)t;
+    nhit = n;
+  }
+  __syncthreads();
+  const int n = nhit;
+  const int x = sx0 + (int)(threadIdx.x % TX), y = sy0 + (int)(threadIdx.x / TX);
+  const bool inside = x < Ws && y < Hs;
+  const bool add = ovf[b] != 0;  // some tile of this sample went through the atomics: keep what they left
+  const long ss = (long)Hs * Ws;
+  float* gp = gsrc + (long)b * C * ss + (long)y * Ws + x;
+  constexpr int CG = 8, EU = 4;  // 8 channels x 4 tiles = 32 independent loads in flight per thread
+  for (int c0 = blockIdx.y * CG; c0 < C; c0 += gridDim.y * CG) {
+    float acc[CG];
+#pragma unroll
+    for (int k = 0; k < CG; ++k) acc[k] = (add && inside && c0 + k < C) ? gp[(long)(c0 + k) * ss] : 0.f;
+    for (int e0 = 0; e0 < n; e0 += EU) {
+      float v[EU][CG];
+      bool in[EU];
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int t = list[min(e0 + u, n - 1)];
+        const int4 mt = m[t];
+        const int rx = x - mt.x, ry = y - mt.y;
+        in[u] = e0 + u < n && inside && rx >= 0 && rx < mt.z && ry >= 0 && ry < mt.w;
+        // every load is issued (a pixel outside the rectangle re-reads the slab's first cell, weight 0)
+        const float* sp = slab + (((long)b * T + t) * C + c0) * (long)cap + (in[u] ? ry * ((mt.z + 3) & ~3) + rx : 0);
+#pragma unroll
+        for (int k = 0; k < CG; ++k) v[u][k] = sp[(long)min(k, C - 1 - c0) * cap];
+      }
+#pragma unroll
+      for (int u = 0; u < EU; ++u)  // tile order
+#pragma unroll
+        for (int k = 0; k < CG; ++k) acc[k] += in[u] ? v[u][k] : 0.f;
+    }
+    if (inside) {
+#pragma unroll
+      for (int k = 0; k < CG; ++k)
+        if (c0 + k < C) gp[(long)(c0 + k) * ss] = acc[k];
+    }
+  }
 }
 }  // namespace lds_scatter
 
@@ -1268,22 +1387,40 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
                              int norm_mode, const double* rows, int nrows, const float* stats, int featnorm_mode,
                              const float* g1n, const float* gdir, long gdir_bs, const float* x1, float* gx1,
                              const float* add1, long add1_bs, const float* add2, float* gcoarse, int up_align,
-                             hipStream_t st) {
-  // gx2, gflow (and gcoarse) arrive ZERO-FILLED (by the correlation backward launch in front of this one)
-  const long tiles = (long)af_cdiv(W, 32) * af_cdiv(H, 8) * B;
+                             float* slab, void* slab_meta, int* slab_ovf, int slab_cap, hipStream_t st) {
+  // gx2, gflow (and gcoarse, slab_ovf) arrive ZERO-FILLED (by the correlation backward launch in front of this one)
+  const long per = (long)af_cdiv(W, 32) * af_cdiv(H, 8);
+  const long tiles = per * B;
   const unsigned nsplit = channel_split(tiles, C);
   const dim3 grid(af_grid_for_tiles(tiles), nsplit);
   LevelBwdArgs la{rows, nrows, featnorm_mode, stats, g1n, gdir, gdir_bs, x1, gx1, gcoarse, up_align};
-  if (tiles * nsplit <= 2048) {  // coarse / middle levels: both roles in one launch
+  // the two-pass slab form of the source gradient is OPT-IN (arflow_level_bwd_ws_bytes only reserves the slabs under
+  // ARFLOW_WARP_SLAB=1): built, parity-green, measured SLOWER at B16 C32 96x160 -- stores 39 us + gather 33 us vs 64 us for
+  // the atomic flush; it is bit-reproducible across workgroup scheduling, the atomics are not
+  const bool want_slab = slab != nullptr && per <= lds_scatter::MAXT;
+  if (tiles * nsplit <= 2048 && !want_slab) {  // both roles in one launch
     hipLaunchKernelGGL(level_warp_bwd_both_kernel, dim3(grid.x, grid.y, 2), dim3(256), 0, st, g2n, x2, x2w, flow, gx2, gflow,
                        B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
     return af_launch_status();
   }
-  hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel<true>, grid, dim3(256), 0, st, g2n, flow, gx2, B, C, H, W, H, W,
-                     flow_bstride, pad_mode, align_corners, norm_mode, x2w, rows, nrows, stats, featnorm_mode);
+  // fine level: the source gradient in the two-pass slab form (stores + gather) when the workspace is there
+  const bool use_slab = want_slab;
+  if (use_slab) {
+    const lds_scatter::SlabArgs sl{slab, (int4*)slab_meta, slab_ovf, slab_cap};
+    hipLaunchKernelGGL((lds_scatter::warp_bwd_src_kernel<true, true>), grid, dim3(256), 0, st, g2n, flow, gx2, B, C, H, W, H, W,
+                       flow_bstride, pad_mode, align_corners, norm_mode, x2w, rows, nrows, stats, featnorm_mode, sl);
+  } else {
+    hipLaunchKernelGGL(lds_scatter::warp_bwd_src_kernel<true>, grid, dim3(256), 0, st, g2n, flow, gx2, B, C, H, W, H, W,
+                       flow_bstride, pad_mode, align_corners, norm_mode, x2w, rows, nrows, stats, featnorm_mode);
+  }
   AF_LAUNCH_CHECK();
   hipLaunchKernelGGL(level_warp_bwd_flow_kernel, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
                      pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
+  if (use_slab) {
+    AF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lds_scatter::slab_gather_kernel, dim3(af_grid_for_tiles(tiles), C >= 32 ? 2 : 1), dim3(256), 0, st, slab,
+                       (const int4*)slab_meta, slab_ovf, gx2, B, C, H, W, (int)per, slab_cap);
+  }
   return af_launch_status();
 }
 
