@@ -10,14 +10,22 @@ namespace {
 constexpr int NT = 256, EPT = 16;  // elements per thread (4 float4)
 
 // y = lrelu(x + bias[c]); x, y: [B, C, HW] (may alias).  grid (chunks of a plane, C, B).
+// MOM: the workgroup also leaves (sum y, sum y^2) of its slice as one row of 2 doubles in `mom` ([B][C * gridDim.x][2]):
+// the partial moments of normalize_features (models/pwclite_uflow.py:30-38), taken where the feature map is produced --
+// the level kernels (level.hip) then need no pass over the first feature map for them.
+template <bool MOM>
 __global__ __launch_bounds__(NT) void bias_act_fwd_kernel(const float* x, const float* __restrict__ bias, float* y,
-                                                          int C, long HW, float slope) {
+                                                          int C, long HW, float slope, double* __restrict__ mom) {
+  __shared__ double dred[2 * (NT / 64)];
   const int c = blockIdx.y;
   const long base = ((long)blockIdx.z * C + c) * HW;
   const float bv = bias ? bias[c] : 0.f;
+  float s = 0.f, q = 0.f;  // <= 16 values per thread in fp32, double from the wave reduction on
   auto f = [&](float v) {
     v += bv;
-    return v > 0.f ? v : v * slope;
+    v = v > 0.f ? v : v * slope;
+    if (MOM) s += v, q = fmaf(v, v, q);
+    return v;
   };
   if ((HW & 3) == 0) {
     const long n4 = HW / 4;
@@ -32,6 +40,19 @@ __global__ __launch_bounds__(NT) void bias_act_fwd_kernel(const float* x, const 
   } else {
     for (long i = (long)blockIdx.x * NT * EPT + threadIdx.x; i < min(HW, ((long)blockIdx.x + 1) * NT * EPT); i += NT)
       y[base + i] = f(x[base + i]);
+  }
+  if (MOM) {
+    double ds = (double)s, dq = (double)q;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off, 64), dq += __shfl_xor(dq, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) dred[2 * wave] = ds, dred[2 * wave + 1] = dq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* row = mom + 2 * (((long)blockIdx.z * C + c) * gridDim.x + blockIdx.x);
+      row[0] = (dred[0] + dred[2]) + (dred[4] + dred[6]);
+      row[1] = (dred[1] + dred[3]) + (dred[5] + dred[7]);
+    }
   }
 }
 
@@ -77,8 +98,23 @@ extern "C" int arflow_bias_act_fwd(const float* x, const float* bias, float* y, 
   AF_REQUIRE_PTR(x);
   AF_REQUIRE_PTR(y);
   AF_REQUIRE(B > 0 && C > 0 && HW > 0 && B <= 65535 && C <= 65535, ARFLOW_ESHAPE);
-  hipLaunchKernelGGL(bias_act_fwd_kernel, dim3(af_cdiv(HW, NT * EPT), C, B), dim3(NT), 0, (hipStream_t)stream, x, bias, y, C,
-                     HW, negative_slope);
+  hipLaunchKernelGGL(bias_act_fwd_kernel<false>, dim3(af_cdiv(HW, NT * EPT), C, B), dim3(NT), 0, (hipStream_t)stream, x, bias, y, C,
+                     HW, negative_slope, (double*)nullptr);
+  return af_launch_status();
+}
+
+// As arflow_bias_act_fwd; additionally the partial moments (sum y, sum y^2) per workgroup: mom holds
+// [B][arflow_bias_act_mom_rows(C, HW)][2] doubles (every row written by the call).
+extern "C" int arflow_bias_act_mom_rows(int C, long HW) { return (C > 0 && HW > 0) ? C * af_cdiv(HW, NT * EPT) : ARFLOW_ESHAPE; }
+extern "C" int arflow_bias_act_fwd_mom(const float* x, const float* bias, float* y, double* mom, int B, int C, long HW,
+                                       float negative_slope, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(x);
+  AF_REQUIRE_PTR(y);
+  AF_REQUIRE_PTR(mom);
+  AF_REQUIRE(B > 0 && C > 0 && HW > 0 && B <= 65535 && C <= 65535, ARFLOW_ESHAPE);
+  hipLaunchKernelGGL(bias_act_fwd_kernel<true>, dim3(af_cdiv(HW, NT * EPT), C, B), dim3(NT), 0, (hipStream_t)stream, x, bias, y, C,
+                     HW, negative_slope, mom);
   return af_launch_status();
 }
 

@@ -403,8 +403,9 @@ static int corr_fwd_impl(const float* x1, const float* x2, float* out, long out_
 // internal launchers for the level entry points (level.hip)
 int af_level_corr_fwd_launch(const float* x1, const float* x2w, const double* acc, int acc_rows, int norm_mode, float* out,
                              long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits, float* stats, int B, int C,
-                             int H, int W, float negative_slope, hipStream_t st) {
-  const corr_v2::NormArgs na{acc, acc_rows, norm_mode, x1n, x1n_bstride, stats};
+                             int H, int W, float negative_slope, hipStream_t st, const double* r1, int n1, const double* r2,
+                             int n2) {
+  const corr_v2::NormArgs na{acc, acc_rows, norm_mode, x1n, x1n_bstride, stats, r1, n1, r2, n2};
   return corr_v2::launch_fwd(x1, x2w, out, sign_bits, B, C, H, W, negative_slope, st, out_bstride, &na);
 }
 int af_level_corr_bwd_launch(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
@@ -435,7 +436,7 @@ extern "C" int arflow_level_corr_fwd(const float* x1, const float* x2w, const do
   const long vol = (long)corr_v2::N * corr_v2::N * H * W;
   AF_REQUIRE(out_bstride >= vol && out_bstride % 4 == 0, ARFLOW_ESHAPE);
   AF_REQUIRE(x1n == nullptr || (x1n_bstride >= (long)C * H * W && x1n_bstride % 4 == 0), ARFLOW_ESHAPE);
-  const corr_v2::NormArgs na{acc, acc_rows, norm_mode, x1n, x1n_bstride, stats};
+  const corr_v2::NormArgs na{acc, acc_rows, norm_mode, x1n, x1n_bstride, stats, nullptr, 0, nullptr, 0};
   return corr_v2::launch_fwd(x1, x2w, out, sign_bits, B, C, H, W, negative_slope, (hipStream_t)stream, out_bstride, &na);
 }
 

@@ -125,6 +125,10 @@ struct NormArgs {
   float* x1n;         // normalised first map out (batch stride x1n_bs floats), may be null
   long x1n_bs;
   float* stats;       // [B][4] (m1, m2, mu, sigma) for the backward
+  const double* r1;   // optional [B][n1][2] rows of the first map's moments (conv epilogue), replacing acc's columns 0, 1
+  int n1;
+  const double* r2;   // the same for the second map (level without a warp)
+  int n2;
 };
 
 template <int NBUF, int G, bool NORM = false>
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(NT * G, (NBUF == 4 && G == 1) ? 2 : 3) void fwd_ker
   if constexpr (NORM) {
     featnorm::Moments m;
     m.m1 = m.m2 = m.mu = 0.f, m.var = 1.f;
-    if (na.nrows > 0) m = featnorm::moments_of(na.acc + 4L * na.nrows * b, na.nrows, (long)C * cs, na.mode);
+    if (na.nrows > 0 || na.r1)
+      m = featnorm::moments_of(featnorm::MomentSrc{na.acc, na.nrows, na.r1, na.n1, na.r2, na.n2}, b, (long)C * cs, na.mode);
     const float sd = sqrtf(m.var + 1e-16f);
     mu = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m.mu)));
     rs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / sd)));
@@ -624,7 +629,7 @@ inline bool eligible(int C, int W, int max_disp) { return max_disp == 4 && (W % 
 inline int launch_fwd(const float* x1, const float* x2, float* out, unsigned* sign_bits, int B, int C, int H, int W,
                       float slope, hipStream_t st, long obs = 0, const NormArgs* norm = nullptr) {
   if (obs == 0) obs = (long)N * N * H * W;
-  const NormArgs na = norm ? *norm : NormArgs{nullptr, 0, 0, nullptr, 0, nullptr};
+  const NormArgs na = norm ? *norm : NormArgs{nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, 0};
   const int tiles = af_cdiv(W, TW) * af_cdiv(H, TH) * B;
   dim3 grid(grid_for_tiles(tiles));
   // many tiles: 4 workgroups per CU hide each other's DMA latency, keep LDS small (2 buffers);

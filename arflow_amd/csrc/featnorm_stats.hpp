@@ -56,6 +56,34 @@ __device__ __forceinline__ Moments moments_of(const double* rows, int nrows, lon
   return moments_from_totals(a, n, mode);
 }
 
+// sum of `nrows` rows of 2 doubles (the rows arflow_bias_act_fwd_mom leaves): one row per lane + wave reduction
+__device__ __forceinline__ void sum_rows2(const double* rows, int nrows, double& s, double& q) {
+  s = 0.0, q = 0.0;
+  for (int r = threadIdx.x & 63; r < nrows; r += 64) s += rows[2 * r], q += rows[2 * r + 1];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64), q += __shfl_xor(q, off, 64);
+}
+
+// The sample's statistics from up to three partial-moment sources: `acc` rows of 4 doubles (sum x1, sum x1^2, sum x2,
+// sum x2^2; the warp launch / moment pass), and optional 2-column rows for the first (`r1`) and the second map (`r2`)
+// taken in the conv epilogue that produced them (they REPLACE the corresponding columns of acc; acc may be null when both
+// are given).
+struct MomentSrc {
+  const double* acc;
+  int nrows;
+  const double* r1;
+  int n1;
+  const double* r2;
+  int n2;
+};
+__device__ __forceinline__ Moments moments_of(const MomentSrc& m, int b, long n, int mode) {
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  if (m.acc && m.nrows > 0) sum_rows<4>(m.acc + 4L * m.nrows * b, m.nrows, a);
+  if (m.r1) sum_rows2(m.r1 + 2L * m.n1 * b, m.n1, a[0], a[1]);
+  if (m.r2) sum_rows2(m.r2 + 2L * m.n2 * b, m.n2, a[2], a[3]);
+  return moments_from_totals(a, n, mode);
+}
+
 // sum over the block of NV doubles per thread; result in thread 0.  scratch: NV * NTH / 64 doubles.
 template <int NV, int NTH>
 __device__ __forceinline__ void block_sum_f64(double (&v)[NV], double* scratch) {

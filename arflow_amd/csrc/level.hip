@@ -52,13 +52,37 @@ extern "C" long arflow_level_bwd_ws_bytes(int B, int C, int H, int W) {
   return (long)bwd_layout(B, C, H, W).total;
 }
 
+extern "C" int arflow_level_fwd_m(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                                  int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
+                                  int norm_mode, float* out, long out_bstride, float* x1n, long x1n_bstride,
+                                  unsigned* sign_bits, float* stats, double* acc, const double* x1_rows, int x1_nrows,
+                                  const double* x2_rows, int x2_nrows, int B, int C, int H, int W, int max_disp,
+                                  float negative_slope, int pad_mode, int align_corners, int coord_norm,
+                                  arflow_stream_t stream);
 extern "C" int arflow_level_fwd(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
                                 int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
                                 int norm_mode, float* out, long out_bstride, float* x1n, long x1n_bstride,
                                 unsigned* sign_bits, float* stats, double* acc, int B, int C, int H, int W, int max_disp,
                                 float negative_slope, int pad_mode, int align_corners, int coord_norm,
                                 arflow_stream_t stream) {
+  return arflow_level_fwd_m(x1, x2, flow, flow_bstride, flow_is_coarse, up_align_corners, flow_up, flow_up2, flow_up2_bstride,
+                            x2w, norm_mode, out, out_bstride, x1n, x1n_bstride, sign_bits, stats, acc, nullptr, 0, nullptr, 0,
+                            B, C, H, W, max_disp, negative_slope, pad_mode, align_corners, coord_norm, stream);
+}
+
+// As arflow_level_fwd, with the partial moments of the feature maps taken where the maps were PRODUCED
+// (arflow_bias_act_fwd_mom rows, [B][nrows][2] doubles): x1_rows for the first map -- the warp launch then does not read it
+// at all -- and, at the level without a warp, x2_rows for the second (no moment pass: the level is one launch).
+extern "C" int arflow_level_fwd_m(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                                  int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
+                                  int norm_mode, float* out, long out_bstride, float* x1n, long x1n_bstride,
+                                  unsigned* sign_bits, float* stats, double* acc, const double* x1_rows, int x1_nrows,
+                                  const double* x2_rows, int x2_nrows, int B, int C, int H, int W, int max_disp,
+                                  float negative_slope, int pad_mode, int align_corners, int coord_norm,
+                                  arflow_stream_t stream) {
   af_clear_stale_error();
+  AF_REQUIRE(x1_rows == nullptr || x1_nrows > 0, ARFLOW_ESHAPE);
+  AF_REQUIRE(x2_rows == nullptr || (x2_nrows > 0 && flow == nullptr && x1_rows != nullptr), ARFLOW_EPARAM);
   AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
   AF_REQUIRE_PTR(out);
@@ -80,7 +104,7 @@ extern "C" int arflow_level_fwd(const float* x1, const float* x2, const float* f
     return af_level_small_fwd_launch(x1, x2, flow, flow_bstride, flow_is_coarse, up_align_corners, flow_up, flow_up2,
                                      flow_up2_bstride, x2w, norm_mode, out, out_bstride, x1n, x1n_bstride,
                                      negative_slope == 1.0f ? nullptr : sign_bits, stats, B, C, H, W, negative_slope,
-                                     pad_mode, align_corners, coord_norm, st);
+                                     pad_mode, align_corners, coord_norm, st, x1_rows, x1_nrows, x2_rows, x2_nrows);
   if (flow) {
     AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
     AF_REQUIRE(coord_norm == ARFLOW_NORM_ARFLOW || coord_norm == ARFLOW_NORM_UFLOW, ARFLOW_EPARAM);
@@ -91,15 +115,17 @@ extern "C" int arflow_level_fwd(const float* x1, const float* x2, const float* f
     } else {
       AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
     }
-    const int rc = af_level_warp_fwd_launch(x1, x2, flow, flow_bstride, flow_is_coarse, up_align_corners, flow_up, flow_up2,
-                                            flow_up2_bstride, x2w, acc, B, C, H, W, pad_mode, align_corners, coord_norm, st);
+    const int rc = af_level_warp_fwd_launch(x1_rows ? nullptr : x1, x2, flow, flow_bstride, flow_is_coarse, up_align_corners,
+                                            flow_up, flow_up2, flow_up2_bstride, x2w, acc, B, C, H, W, pad_mode, align_corners,
+                                            coord_norm, st);
     if (rc != ARFLOW_OK) return rc;
-  } else {
+  } else if (!x2_rows) {
     const int rc = af_featnorm_moments_launch(x1, x2, acc, B, (long)C * H * W, st);
     if (rc != ARFLOW_OK) return rc;
   }
-  return af_level_corr_fwd_launch(x1, flow ? x2w : x2, acc, rows, norm_mode, out, out_bstride, x1n, x1n_bstride,
-                                  negative_slope == 1.0f ? nullptr : sign_bits, stats, B, C, H, W, negative_slope, st);
+  return af_level_corr_fwd_launch(x1, flow ? x2w : x2, (flow || !x2_rows) ? acc : nullptr, (flow || !x2_rows) ? rows : 0,
+                                  norm_mode, out, out_bstride, x1n, x1n_bstride, negative_slope == 1.0f ? nullptr : sign_bits,
+                                  stats, B, C, H, W, negative_slope, st, x1_rows, x1_nrows, x2_rows, x2_nrows);
 }
 
 extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,

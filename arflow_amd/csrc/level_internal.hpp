@@ -27,7 +27,8 @@ int af_featnorm_bwd_sums_launch(const float* g1, const float* g1b, long g1b_bs, 
 int af_up2_bwd_launch(const float* gfine, float* gcoarse, int planes, int H, int W, int up_align, hipStream_t st);
 int af_level_corr_fwd_launch(const float* x1, const float* x2w, const double* acc, int acc_rows, int norm_mode, float* out,
                              long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits, float* stats, int B, int C,
-                             int H, int W, float negative_slope, hipStream_t st);
+                             int H, int W, float negative_slope, hipStream_t st, const double* r1, int n1, const double* r2,
+                             int n2);
 int af_level_corr_bwd_launch(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n,
                              long x1n_bstride, const float* x2w, const float* stats, float* gx1n, float* gx2n, int B, int C,
                              int H, int W, float negative_slope, hipStream_t st, float* zero_c, float* zero_f,
@@ -39,4 +40,4 @@ int af_level_small_fwd_launch(const float* x1, const float* x2, const float* flo
                               int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
                               int norm_mode, float* out, long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits,
                               float* stats, int B, int C, int H, int W, float negative_slope, int pad_mode, int align_corners,
-                              int coord_norm, hipStream_t st);
+                              int coord_norm, hipStream_t st, const double* r1, int n1, const double* r2, int n2);

@@ -46,6 +46,10 @@ struct FwdArgs {
   int C, H, W;
   float slope;
   int pad, align, norm;
+  const double* r1;  // optional [B][n1][2] partial moments of x1 (conv epilogue); with HAS_FLOW == false also r2 for x2
+  int n1;
+  const double* r2;
+  int n2;
 };
 
 template <bool HAS_FLOW>
@@ -69,11 +73,12 @@ __global__ __launch_bounds__(NT) void fwd_kernel(FwdArgs a) {
   if constexpr (HAS_FLOW) {
     // the whole second map -> LDS, every load of a thread in flight at once
     for (int i = tid; i < C * HW4; i += NT) reinterpret_cast<float4*>(arena)[i] = reinterpret_cast<const float4*>(x2b)[i];
-    for (int i = tid; i < C * HW4; i += NT) {
-      const float4 u = reinterpret_cast<const float4*>(x1b)[i];
-      mom[0] += (u.x + u.y) + (u.z + u.w);
-      mom[1] = fmaf(u.x, u.x, fmaf(u.y, u.y, fmaf(u.z, u.z, fmaf(u.w, u.w, mom[1]))));
-    }
+    if (!a.r1)
+      for (int i = tid; i < C * HW4; i += NT) {
+        const float4 u = reinterpret_cast<const float4*>(x1b)[i];
+        mom[0] += (u.x + u.y) + (u.z + u.w);
+        mom[1] = fmaf(u.x, u.x, fmaf(u.y, u.y, fmaf(u.z, u.z, fmaf(u.w, u.w, mom[1]))));
+      }
     TapPlan tp[2];
     bool act[2];
 #pragma unroll
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(FwdArgs a) {
       }
     }
     __syncthreads();  // the arena is reused below
-  } else {
+  } else if (!(a.r1 && a.r2)) {
     for (int i = tid; i < C * HW4; i += NT) {
       const float4 u = reinterpret_cast<const float4*>(x1b)[i], v = reinterpret_cast<const float4*>(x2b)[i];
       mom[0] += (u.x + u.y) + (u.z + u.w);
@@ -142,7 +147,9 @@ __global__ __launch_bounds__(NT) void fwd_kernel(FwdArgs a) {
   for (int i = tid; i < 2 * CCH * MAXHALO / 4; i += NT) reinterpret_cast<float4*>(xw)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = tid; i < 3 * MAXHW; i += NT) sg[i] = 0u;
   __syncthreads();
-  const double ta[4] = {tot[0], tot[1], tot[2], tot[3]};
+  double ta[4] = {tot[0], tot[1], tot[2], tot[3]};
+  if (a.r1) featnorm::sum_rows2(a.r1 + 2L * a.n1 * b, a.n1, ta[0], ta[1]);  // every wave adds the rows itself
+  if (!HAS_FLOW && a.r1 && a.r2) featnorm::sum_rows2(a.r2 + 2L * a.n2 * b, a.n2, ta[2], ta[3]);
   const featnorm::Moments m = featnorm::moments_from_totals(ta, (long)C * HW, a.mode);
   const float sd = sqrtf(m.var + 1e-16f);
   const float mu = m.mu, rs = 1.0f / sd;
@@ -159,6 +166,50 @@ __global__ __launch_bounds__(NT) void fwd_kernel(FwdArgs a) {
   const bool active = dyl < ndy;
   const int gy = g / W4, gx = 4 * (g - gy * W4), dy = dy0 + dyl;
   float* x1nb = (a.x1n && blockIdx.y == 0) ? a.x1n + (long)b * a.x1n_bs : nullptr;
+
+  float acc[N][PX];
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+#pragma unroll
+    for (int p = 0; p < PX; ++p) acc[j][p] = 0.f;
+  float s1n[PX] = {0.f, 0.f, 0.f, 0.f};
+
+  const int HALO = (H + 2 * D) * WP;
+  const bool oneshot = C * (HW + HALO) <= ARENA;  // both maps fit LDS whole (12x20 at C = 32): no chunk loop, no barriers in it
+  if (oneshot) {
+    // halo tiles [C][HALO] (zero-filled above as far as xw reaches; clear the rest) + normalised first map [C][HW]
+    float* xh = arena;
+    float* xn = arena + C * HALO;
+    for (int i = 2 * CCH * MAXHALO / 4 + tid; i < C * HALO / 4; i += NT) reinterpret_cast<float4*>(arena)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int i = tid; i < C * HW4; i += NT) {
+      const int c = i / HW4, j = i - c * HW4;
+      const int px = 4 * j, y = px / W, x = px - y * W;
+      const float4 v2 = reinterpret_cast<const float4*>(s2b)[i], v1 = reinterpret_cast<const float4*>(x1b)[i];
+      *reinterpret_cast<float4*>(xh + c * HALO + (y + D) * WP + x + D) = v2;
+      const float4 n = make_float4((v1.x - mu) * rs, (v1.y - mu) * rs, (v1.z - mu) * rs, (v1.w - mu) * rs);
+      *reinterpret_cast<float4*>(xn + c * HW + px) = n;
+      if (x1nb) reinterpret_cast<float4*>(x1nb)[i] = n;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 2
+      for (int c = 0; c < C; ++c) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(xn + c * HW + gy * W + gx);
+        const float* wr = xh + c * HALO + (gy + dy) * WP + gx;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4),
+                    w2 = *reinterpret_cast<const f32x4*>(wr + 8);
+        const float win[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+        const float av4[PX] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int p = 0; p < PX; ++p) s1n[p] += av4[p];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+          for (int p = 0; p < PX; ++p) acc[j][p] = fmaf(av4[p], win[j + p], acc[j][p]);
+      }
+    }
+  }
 
   float4 v2[2], v1[2];
   auto load_chunk = [&](int c0) {
@@ -187,17 +238,12 @@ __global__ __launch_bounds__(NT) void fwd_kernel(FwdArgs a) {
     }
   };
 
-  float acc[N][PX];
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-#pragma unroll
-    for (int p = 0; p < PX; ++p) acc[j][p] = 0.f;
-  float s1n[PX] = {0.f, 0.f, 0.f, 0.f};
-
   // (the pass-1 stage aliased x1s: every thread is past it -- the barrier above)
-  load_chunk(0);
-  store_chunk(0, 0);
-  const int nchunk = C / CCH;
+  const int nchunk = oneshot ? 0 : C / CCH;
+  if (!oneshot) {
+    load_chunk(0);
+    store_chunk(0, 0);
+  }
   for (int ch = 0; ch < nchunk; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunk) load_chunk((ch + 1) * CCH);
@@ -275,8 +321,9 @@ int af_level_small_fwd_launch(const float* x1, const float* x2, const float* flo
                               int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,
                               int norm_mode, float* out, long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits,
                               float* stats, int B, int C, int H, int W, float negative_slope, int pad_mode, int align_corners,
-                              int coord_norm, hipStream_t st) {
+                              int coord_norm, hipStream_t st, const double* r1, int n1, const double* r2, int n2) {
   small::FwdArgs a;
+  a.r1 = r1, a.n1 = n1, a.r2 = r2, a.n2 = n2;
   a.x1 = x1, a.x2 = x2, a.flow = flow, a.fbs = flow_bstride, a.flow_is_coarse = flow_is_coarse, a.up_align = up_align_corners;
   a.flow_up = flow_up, a.flow_up2 = flow_up2, a.fu2_bs = flow_up2_bstride, a.x2w = x2w, a.mode = norm_mode;
   a.out = out, a.obs = out_bstride, a.x1n = x1n, a.x1n_bs = x1n_bstride, a.sign = sign_bits, a.stats = stats;

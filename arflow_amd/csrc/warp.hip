@@ -104,7 +104,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
   float xn[CCH];
   auto fetch_x1 = [&](int cc) {
 #pragma unroll
-    for (int c = 0; c < CCH; ++c) xn[c] = (MOM && inside && cc + c < C) ? x1p[(long)(cc + c) * os] : 0.f;
+    for (int c = 0; c < CCH; ++c) xn[c] = (MOM && x1p && inside && cc + c < C) ? x1p[(long)(cc + c) * os] : 0.f;
   };
   const int step = gridDim.y * CCH;  // channels are independent: at small levels they are spread over gridDim.y workgroups
   int c0 = blockIdx.y * CCH;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void level_warp_fwd_kernel(const float* __rest
   const int ss = Hs * Ws, os = H * W;
   const float* sp = src + (long)b * C * ss;
   float* op = out + (long)b * C * os + (long)y * W + x;
-  const float* x1p = x1 + (long)b * C * os + (long)y * W + x;
+  const float* x1p = x1 ? x1 + (long)b * C * os + (long)y * W + x : nullptr;  // null: the first map's moments come from elsewhere
   float mom[4] = {0.f, 0.f, 0.f, 0.f};
 
   if (!empty && (Ws & 3) == 0 && bh <= HMAX && aw <= 72) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void level_warp_fwd_kernel(const float* __rest
           r = p.ok[3] ? fmaf(a3, p.w[3], r) : r;
         }
         op[(long)(c + u) * os] = r;
-        const float xv = x1p[(long)(c + u) * os];
+        const float xv = x1p ? x1p[(long)(c + u) * os] : 0.f;
         mom[0] += xv, mom[1] = fmaf(xv, xv, mom[1]);
         mom[2] += r, mom[3] = fmaf(r, r, mom[3]);
       }
@@ -1330,7 +1330,6 @@ extern "C" int arflow_level_warp_fwd(const float* x1, const float* x2, const flo
                                      long flow_up2_bstride, float* x2w, double* acc, int B, int C, int H, int W,
                                      int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {
   af_clear_stale_error();
-  AF_REQUIRE_PTR(x1);
   AF_REQUIRE_PTR(x2);
   AF_REQUIRE_PTR(flow);
   AF_REQUIRE_PTR(x2w);

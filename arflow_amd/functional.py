@@ -425,7 +425,10 @@ class LevelFunction(torch.autograd.Function):
     (buf, flow_up) with a coarse flow, else buf."""
 
     @staticmethod
-    def forward(ctx, x1, x2, flow, cfg, *members):
+    def forward(ctx, x1, x2, flow, cfg, x1_rows, x2_rows, *members):
+        """x1_rows / x2_rows (optional [B,rows,2] float64): partial moments of x1 / (at a level without flow) x2 from
+        bias_leaky_relu_moments -- the launch that produced the maps; the warp launch then skips reading x1 and the
+        level without a warp needs no moment pass."""
         _need_gpu(x1, x2, flow, *members)
         if x1.shape != x2.shape or x1.dim() != 4:
             raise ValueError('level expects two [B,C,H,W] feature maps of equal shape')
@@ -464,16 +467,24 @@ class LevelFunction(torch.autograd.Function):
         else:
             x1n = torch.empty_like(x1)
             x1n_ptr, x1n_bs = x1n.data_ptr(), C * H * W
+        if x1_rows is not None:
+            if x1_rows.dtype != torch.float64 or x1_rows.shape[0] != B or x1_rows.shape[2] != 2:
+                raise ValueError('x1_rows must be [B, rows, 2] float64')
+            x1_rows = x1_rows.contiguous()
+        if x2_rows is not None:
+            x2_rows = x2_rows.contiguous() if (not has_flow and x1_rows is not None) else None
         with torch.cuda.device_of(x1):
-            _call('arflow_level_fwd', _p(x1), _p(x2), _p(flow), fbs, int(cfg.flow_is_coarse and has_flow), int(cfg.up_align),
+            _call('arflow_level_fwd_m', _p(x1), _p(x2), _p(flow), fbs, int(cfg.flow_is_coarse and has_flow), int(cfg.up_align),
                   _p(fup), fslot, bs, _p(x2w), cfg.mode, buf[:, offs['vol']:].data_ptr(), bs, x1n_ptr, x1n_bs, _p(sign),
-                  _p(stats), _p(acc), B, C, H, W, cfg.d, cfg.slope, cfg.pad, cfg.align, cfg.norm, _stream(),
-                  key=(B, C, H, W, cfg.d, 3 if sign is not None else 0, int(has_flow) + int(has_flow and cfg.flow_is_coarse)))
+                  _p(stats), _p(acc), _p(x1_rows), 0 if x1_rows is None else int(x1_rows.shape[1]), _p(x2_rows),
+                  0 if x2_rows is None else int(x2_rows.shape[1]), B, C, H, W, cfg.d, cfg.slope, cfg.pad, cfg.align, cfg.norm,
+                  _stream(), key=(B, C, H, W, cfg.d, 3 if sign is not None else 0,
+                                  int(has_flow) + int(has_flow and cfg.flow_is_coarse), int(x1_rows is not None)))
         for item in cfg.layout:
             if not isinstance(item, str):
                 buf[:, offs[item]:offs[item] + int(members[item].shape[1])].copy_(members[item])
         ctx.save_for_backward(x1, x2, x2w, flow_full, stats, sign, buf if x1n is None else x1n)
-        ctx.cfg, ctx.offs, ctx.ctot, ctx.n_members, ctx.has_flow = cfg, offs, ctot, len(members), has_flow
+        ctx.cfg, ctx.offs, ctx.ctot, ctx.n_members, ctx.has_flow = cfg, offs, ctot, len(members), has_flow  # noqa
         ctx.member_chans = [int(m.shape[1]) for m in members]
         if has_flow and cfg.flow_is_coarse:
             return buf, flow_full
@@ -516,12 +527,12 @@ class LevelFunction(torch.autograd.Function):
                 gm.append((item, gbuf[:, offs[item]:offs[item] + ctx.member_chans[item]]))
         gmembers = [None] * ctx.n_members
         for idx, g in gm:
-            gmembers[idx] = g if ctx.needs_input_grad[4 + idx] else None
-        return (d1, gx2, gflow_in, None) + tuple(gmembers)
+            gmembers[idx] = g if ctx.needs_input_grad[6 + idx] else None
+        return (d1, gx2, gflow_in, None, None, None) + tuple(gmembers)
 
 
-def level(x1, x2, flow, cfg, *members):
-    return LevelFunction.apply(x1, x2, flow, cfg, *members)
+def level(x1, x2, flow, cfg, *members, x1_rows=None, x2_rows=None):
+    return LevelFunction.apply(x1, x2, flow, cfg, x1_rows, x2_rows, *members)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -563,6 +574,47 @@ class BiasLeakyReLUFunction(torch.autograd.Function):
 
 def bias_leaky_relu(x, bias, slope=0.1):
     return BiasLeakyReLUFunction.apply(x, bias, slope)
+
+
+class BiasLeakyReLUMomentsFunction(torch.autograd.Function):
+    """bias_leaky_relu that also returns the partial moments (sum y, sum y^2) of its output as rows of 2 doubles
+    ([B, rows, 2], arflow_bias_act_fwd_mom): normalize_features' moments taken where the feature map is produced."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope):
+        _need_gpu(x)
+        if not x.is_contiguous():
+            raise ValueError('bias_leaky_relu expects a contiguous [B,C,...] tensor')
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        if bias is not None:
+            _need_gpu(bias)
+            bias = bias.contiguous()
+        rows = _lib.load().arflow_bias_act_mom_rows(C, hw)
+        mom = torch.empty(B, rows, 2, device=x.device, dtype=torch.float64)
+        with torch.cuda.device_of(x):
+            _call('arflow_bias_act_fwd_mom', _p(x), _p(bias), _p(x), _p(mom), B, C, hw, float(slope), _stream(), key=(B, C, hw))
+        ctx.mark_dirty(x)
+        ctx.mark_non_differentiable(mom)
+        ctx.save_for_backward(x)
+        ctx.slope, ctx.has_bias = float(slope), bias is not None
+        return x, mom
+
+    @staticmethod
+    def backward(ctx, gout, gmom_unused):
+        y, = ctx.saved_tensors
+        B, C = y.shape[0], y.shape[1]
+        hw = y[0, 0].numel()
+        gout = gout.contiguous()
+        gin = torch.empty_like(gout)
+        gb = torch.empty(C, device=y.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        with torch.cuda.device_of(y):
+            _call('arflow_bias_act_bwd', _p(gout), _p(y), _p(gin), _p(gb), B, C, hw, ctx.slope, _stream(), key=(B, C, hw))
+        return gin, gb, None
+
+
+def bias_leaky_relu_moments(x, bias, slope=0.1):
+    return BiasLeakyReLUMomentsFunction.apply(x, bias, slope)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -15,9 +15,16 @@ class ConvAct(nn.Sequential):
     LeakyReLU-derivative/bias-gradient pass backward) instead of conv, bias add, LeakyReLU and a separate
     full-tensor reduction for the bias gradient."""
 
+    want_moments = False  # set on the conv that OUTPUTS a pyramid level: its epilogue also leaves that map's moments
+    last_moments = None
+
     def forward(self, x):
         c, act = self[0], self[1]
         y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        if self.want_moments and y.is_cuda and bias_act is AF.bias_leaky_relu:
+            y, self.last_moments = AF.bias_leaky_relu_moments(y, c.bias, act.negative_slope)
+            return y
+        self.last_moments = None
         return bias_act(y, c.bias, act.negative_slope)
 
 
@@ -40,22 +47,29 @@ class FeatureExtractor(nn.Module):
     """models/pwclite.py:26-45 (2 convs per level) / models/pwclite_uflow.py:40-62 (3 convs per level,
     input rescaled to [-1,1])."""
 
-    def __init__(self, num_chs, convs_per_level=2, rescale_input=False):
+    def __init__(self, num_chs, convs_per_level=2, rescale_input=False, moments=False):
+        """moments=True (not in the reference's signature): the last conv of every level also leaves the partial moments
+        of its output (normalize_features' sums, taken in the fused bias/LeakyReLU epilogue) in `pyramid_moments`,
+        coarsest first like the pyramid -- [B, rows, 2] float64 per level, or None off the GPU path."""
         super().__init__()
         self.num_chs = num_chs
         self.rescale_input = rescale_input
         self.convs = nn.ModuleList()
         for ch_in, ch_out in zip(num_chs[:-1], num_chs[1:]):
             layers = [conv(ch_in, ch_out, stride=2)] + [conv(ch_out, ch_out) for _ in range(convs_per_level - 1)]
+            layers[-1].want_moments = bool(moments)
             self.convs.append(nn.Sequential(*layers))
+        self.pyramid_moments = None
 
     def forward(self, x):
         if self.rescale_input:
             x = x * 2. - 1.
-        pyramid = []
+        pyramid, moms = [], []
         for level in self.convs:
             x = level(x)
             pyramid.append(x)
+            moms.append(level[-1].last_moments)
+        self.pyramid_moments = moms[::-1]
         return pyramid[::-1]
 
 

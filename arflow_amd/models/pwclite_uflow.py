@@ -7,7 +7,7 @@ from .. import functional as AF
 from ..correlation import Correlation
 from ..warp_utils import flow_warp
 from .blocks import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, FlowEstimatorReduce, deconv,
-                     init_conv_weights, pair_batches)
+                     init_conv_weights)
 
 
 def normalize_features(features_list):
@@ -37,7 +37,8 @@ class PWCLiteUflow(nn.Module):
         self.feature_norm = cfg.feature_norm
         self.align_corners = cfg.align_corners
         self.warp_pad = cfg.warp_pad
-        self.feature_pyramid_extractor = FeatureExtractor(self.num_chs, convs_per_level=3, rescale_input=True)
+        self.feature_pyramid_extractor = FeatureExtractor(self.num_chs, convs_per_level=3, rescale_input=True,
+                                                          moments=bool(cfg.feature_norm))
         self.n_frames = cfg.n_frames
         self.reduce_dense = cfg.reduce_dense
         # opt-in: cfg.feature_storage = 'bf16' keeps the correlation / warp inputs as bf16 in HBM (fp32 arithmetic);
@@ -74,8 +75,9 @@ class PWCLiteUflow(nn.Module):
         t = t.repeat_interleave(batch_per_pass, dim=0).t().contiguous()  # [n, passes*B]
         return t.to(device, non_blocking=True).view(n, -1, 1, 1, 1)
 
-    def forward_2_frames(self, x1_pyramid, x2_pyramid, drops=None):
-        """models/pwclite_uflow.py:193-252."""
+    def forward_2_frames(self, x1_pyramid, x2_pyramid, drops=None, moments=None):
+        """models/pwclite_uflow.py:193-252.  moments: optional (x1 rows, x2 rows) lists per pyramid level, the feature maps'
+        partial moments from the extractor's conv epilogues (FeatureExtractor(moments=True))."""
         flows = []
         b, _, h, w = x1_pyramid[0].shape
         flow = torch.zeros(b, 2, h, w, dtype=torch.float32, device=x1_pyramid[0].device)
@@ -86,13 +88,15 @@ class PWCLiteUflow(nn.Module):
                     and AF.level_supported(x1, None if l == 0 else flow, True, self.search_range)):
                 # the whole level in front of the estimator as two launches: flow upsample +
                 # warp + moments, then the cost volume of the normalised pair straight from the raw maps
+                r1 = moments[0][l] if moments is not None else None
+                r2 = moments[1][l] if moments is not None else None
                 if l == 0:
                     cfg = AF.LevelCfg(['vol', 'x1n', 0], 'joint', 0.1, self.search_range)
-                    est_in = AF.level(x1, x2, None, cfg, flow)
+                    est_in = AF.level(x1, x2, None, cfg, flow, x1_rows=r1, x2_rows=r2)
                 else:
                     cfg = AF.LevelCfg(['vol', 'x1n', 'flow', 0], 'joint', 0.1, self.search_range, True, self.align_corners,
                                       self.warp_pad, self.align_corners)
-                    est_in, flow = AF.level(x1, x2, flow, cfg, self.deconv_networks[l - 1](act))
+                    est_in, flow = AF.level(x1, x2, flow, cfg, self.deconv_networks[l - 1](act), x1_rows=r1)
             else:
                 if l == 0:
                     x2_warp = x2
@@ -128,14 +132,21 @@ class PWCLiteUflow(nn.Module):
         B = x.size(0)
         imgs = [x[:, 0:3], x[:, 3:6]]
         pyr_all = self.feature_pyramid_extractor(torch.cat(imgs, 0))
+        moms = self.feature_pyramid_extractor.pyramid_moments
+        have_m = moms is not None and all(t is not None for t in moms)
         p1 = [p[:B] for p in pyr_all] + [imgs[0]]
         p2 = [p[B:] for p in pyr_all] + [imgs[1]]
         res = {}
         if with_bk:
-            a, b = pair_batches(p1, p2)
-            flows = self.forward_2_frames(a, b, self._drops(2, B, x.device))
+            # first maps of the 2B (fw; bw) samples = the extractor's batch as it stands (no copy); second maps = its
+            # two halves swapped; the same holds for the rows of partial moments
+            a = list(pyr_all)  # (the image level the reference appends to its pyramids is never read, pwclite_uflow.py:203)
+            b = [torch.cat([p[B:], p[:B]], 0) for p in pyr_all]
+            m = ([t for t in moms], [torch.roll(t, B, 0) for t in moms]) if have_m else None
+            flows = self.forward_2_frames(a, b, self._drops(2, B, x.device), m)
             res['flows_fw'] = [f[:B] for f in flows]
             res['flows_bw'] = [f[B:] for f in flows]
         else:
-            res['flows_fw'] = self.forward_2_frames(p1, p2, self._drops(1, B, x.device))
+            m = ([t[:B] for t in moms], [t[B:] for t in moms]) if have_m else None
+            res['flows_fw'] = self.forward_2_frames(p1, p2, self._drops(1, B, x.device), m)
         return res

@@ -60,8 +60,8 @@ _use_shipped_miopen_db()
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HOST_GLUE = ('arflow_bias_act_fwd', 'arflow_bias_act_bwd')
-COMPOSITE_CALLS = ('arflow_level_fwd', 'arflow_level_bwd')  # entry points that launch several kernels back to back
+HOST_GLUE = ('arflow_bias_act_fwd', 'arflow_bias_act_bwd', 'arflow_bias_act_fwd_mom')
+COMPOSITE_CALLS = ('arflow_level_fwd', 'arflow_level_fwd_m', 'arflow_level_bwd')  # entry points that launch several kernels back to back
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
@@ -89,8 +89,8 @@ def algorithmic_bytes(name, shape):
     if name == 'arflow_warp_bwd_bf16':
         B, C, H, W, with_src = shape
         return B * H * W * (4 * C + 2 * C + 16 + (4 * C if with_src else 0))
-    if name == 'arflow_level_fwd':  # raw x1, x2 in; x2w (with a flow), volume + sign words, normalised x1 out; flow in/out
-        B, C, H, W, d, act, fk = shape
+    if name in ('arflow_level_fwd', 'arflow_level_fwd_m'):  # raw x1, x2 in; x2w (with a flow), volume + sign words, normalised x1 out; flow in/out
+        B, C, H, W, d, act, fk = shape[:7]
         flow = {0: 0.0, 1: 2.0, 2: 0.5 + 4.0}[fk]
         return int(4 * B * H * W * (2 * C + (C if fk else 0) + (2 * d + 1) ** 2 + act + C + flow))
     if name == 'arflow_level_bwd':  # gvol + signs, x1n, its direct gradient, x1, x2 (+ x2w, flow) in; gx1, gx2 (+ gflow) out
@@ -117,7 +117,7 @@ def algorithmic_bytes(name, shape):
     if name == 'arflow_featnorm_bwd':
         B, n = shape
         return 4 * B * n * 6  # g1, g2, x1, x2 in; gx1, gx2 out
-    if name == 'arflow_bias_act_fwd':
+    if name in ('arflow_bias_act_fwd', 'arflow_bias_act_fwd_mom'):
         B, C, hw = shape
         return 4 * B * C * hw * 2
     if name == 'arflow_bias_act_bwd':
@@ -198,7 +198,7 @@ def valu_slots(name, shape, trans_slots=None):
     if name == 'arflow_photo_bwd':
         B, C, H, W = shape  # window coefficients (as forward) + 9 windows x 3 fma per pixel
         return B * C * H * W * (5 + 45 + 45 + 2 * T + 27)
-    if name in ('arflow_corr_fwd', 'arflow_corr_fwd_strided', 'arflow_level_corr_fwd', 'arflow_level_fwd'):
+    if name in ('arflow_corr_fwd', 'arflow_corr_fwd_strided', 'arflow_level_corr_fwd', 'arflow_level_fwd', 'arflow_level_fwd_m'):
         B, C, H, W, d = shape[:5]
         return B * H * W * (2 * d + 1) ** 2 * C
     if name in ('arflow_corr_bwd', 'arflow_corr_bwd_strided', 'arflow_level_corr_bwd', 'arflow_level_bwd'):

@@ -165,6 +165,15 @@ int arflow_level_fwd(const float* x1, const float* x2, const float* flow, long f
                      float* out, long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits, float* stats,
                      double* acc, int B, int C, int H, int W, int max_disp, float negative_slope, int pad_mode,
                      int align_corners, int coord_norm, arflow_stream_t stream);
+/* As arflow_level_fwd, with the partial moments of the feature maps taken where the maps were PRODUCED
+ * (arflow_bias_act_fwd_mom rows, [B][nrows][2] doubles of (sum, sum of squares)): x1_rows for the first map (the warp launch
+ * then does not read it) and, at the level without a warp, x2_rows for the second (no moment pass at all). */
+int arflow_level_fwd_m(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
+                       int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w, int norm_mode,
+                       float* out, long out_bstride, float* x1n, long x1n_bstride, unsigned* sign_bits, float* stats,
+                       double* acc, const double* x1_rows, int x1_nrows, const double* x2_rows, int x2_nrows, int B, int C, int H,
+                       int W, int max_disp, float negative_slope, int pad_mode, int align_corners, int coord_norm,
+                       arflow_stream_t stream);
 int arflow_level_bwd(const float* gout, long gout_bstride, const unsigned* sign_bits, const float* x1n, long x1n_bstride,
                      const float* gx1n_direct, long gx1n_direct_bstride, const float* x1, const float* x2, const float* x2w,
                      const float* flow_full, long flow_bstride, const float* gflow_a, long gflow_a_bstride,
@@ -195,6 +204,12 @@ int arflow_level_corr_bwd(const float* gout, long gout_bstride, const unsigned* 
  * gbias[c] = sum_{b,hw} gin (gbias nullable, zero-filled here; fp32 atomics). */
 int arflow_bias_act_fwd(const float* x, const float* bias, float* y, int B, int C, long HW,
                         float negative_slope, arflow_stream_t stream);
+/* As arflow_bias_act_fwd; additionally every workgroup leaves (sum y, sum y^2) of its slice: mom holds
+ * [B][arflow_bias_act_mom_rows(C, HW)][2] doubles (every row written by the call) -- the partial moments of
+ * normalize_features taken where the feature map is produced (arflow_level_fwd_m consumes them). */
+int arflow_bias_act_mom_rows(int C, long HW);
+int arflow_bias_act_fwd_mom(const float* x, const float* bias, float* y, double* mom, int B, int C, long HW,
+                            float negative_slope, arflow_stream_t stream);
 int arflow_bias_act_bwd(const float* gout, const float* y, float* gin, float* gbias, int B, int C, long HW,
                         float negative_slope, arflow_stream_t stream);
 
