@@ -23,6 +23,7 @@
 // halo = 1.5 x the tile, 4 taps each) are served by L2 and overlap other workgroups' arithmetic.
 #include <cstdlib>
 
+#include "census_col.hpp"
 #include "census_tile.hpp"
 #include "smooth_dev.hpp"
 #include "taps.hpp"
@@ -30,6 +31,7 @@
 namespace {
 namespace census_warp {
 using namespace census4;
+using census_col::up4_clamped;
 
 // plain grey tile from a [H,W] plane: rows [ty0-R, ty0+TYH+R), columns [tx0-4, tx0+TXW+4), zero outside
 template <int R>
@@ -100,18 +102,6 @@ __device__ __forceinline__ void zero_margins(float* __restrict__ tile) {
     const int r = i / (2 * M), c = i - r * (2 * M);
     tile[r * PITCH + (c < M ? c : TXW + 4 + R + (c - M))] = 0.f;
   }
-}
-
-// upsample(clamp(occ, 0, 1), x4)[y, x]: torch bilinear, align_corners=False (as up4_clamp_mul_kernel, smooth.hip)
-__device__ __forceinline__ float up4_clamped(const float* __restrict__ occ, int h, int w, int y, int x) {
-  const float sy = fmaxf(0.25f * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.25f * ((float)x + 0.5f) - 0.5f, 0.f);
-  const int y0 = (int)sy, x0 = (int)sx;
-  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-  const float ly = sy - (float)y0, lx = sx - (float)x0;
-  auto cl = [](float v) { return fminf(fmaxf(v, 0.f), 1.f); };
-  const float v00 = cl(occ[(long)y0 * w + x0]), v01 = cl(occ[(long)y0 * w + x1]);
-  const float v10 = cl(occ[(long)y1 * w + x0]), v11 = cl(occ[(long)y1 * w + x1]);
-  return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
 template <int R>
@@ -360,6 +350,24 @@ static bool use_sym() {
   const char* e = getenv("ARFLOW_CENSUS_SYM");
   return e && e[0] == '1';
 }
+// The pair-shared column kernels (census_col.hpp) are the default; ARFLOW_CENSUS_COL=0 selects the ordered-pair kernels of
+// this file (tests run both, tools/kbench.py times both).
+static bool use_col(bool backward = false) {
+  const char* e = getenv("ARFLOW_CENSUS_COL");  // 0: neither, f: forward only, 1 / unset: both
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == 'f') return !backward;
+  return true;
+}
+// census_col.hip
+int census_col_fwd(const float* gray_a, const float* gray_b, const float* flow, long fbs, const float* occ_small,
+                   float* mask_out, float* dham, float* sums, int nrows, int B, int H, int W, int radius, int pair,
+                   hipStream_t st);
+int census_col_bwd(const float* gray_a, const float* gray_b, const float* flow, long fbs, const float* dham,
+                   const float* scale, float* gflow, int B, int H, int W, int radius, int pair, hipStream_t st);
+int census_col_pair_bwd_smooth(const float* gray, const float* flow, long fbs, const float* dham, const float* scale2,
+                               float* gflow, int B2, int H, int W, int radius, const float* flow2, long flow2_bstride,
+                               const float* img2, int h2, int w2, float flow_scale, float alpha, int order, int wmode,
+                               int penalty, const float* coef2, float* gflow2, hipStream_t st);
 
 extern "C" int arflow_census_warp_supported(int H, int W) { return (W % 4 == 0 && H % 4 == 0 && H >= 8 && W >= 8) ? 1 : 0; }
 
@@ -394,6 +402,8 @@ static int census_warp_fwd_impl(const float* gray_a, const float* gray_b, const 
   const int nrows = af_sums_rows(B, H, W);
   if (use_sym() && !pair) return census_sym_fwd(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, radius, st);
   namespace cw = census_warp;
+  if (use_col())
+    return census_col_fwd(gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, radius, pair, st);
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B));
   switch (radius) {
     case 1: hipLaunchKernelGGL(cw::fwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, occ_small, mask_out, dham, sums, nrows, B, H, W, pair); break;
@@ -435,6 +445,7 @@ static int census_warp_bwd_impl(const float* gray_a, const float* gray_b, const 
   hipStream_t st = (hipStream_t)stream;
   if (use_sym() && !pair) return census_sym_bwd(gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, radius, st);
   namespace cw = census_warp;
+  if (use_col(true)) return census_col_bwd(gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, radius, pair, st);
   dim3 g(af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B));
   switch (radius) {
     case 1: hipLaunchKernelGGL(cw::bwd_kernel<1>, g, dim3(cw::NT), 0, st, gray_a, gray_b, flow, flow_bstride, dham, scale, gflow, B, H, W, pair); break;
@@ -480,10 +491,12 @@ extern "C" int arflow_uflow_pair_bwd(const float* gray, const float* flow, long 
   AF_REQUIRE(radius >= 1 && radius <= 3, ARFLOW_EPARAM);
   AF_REQUIRE((order == 1 || order == 2) && (wmode == 0 || wmode == 1) && (penalty == 0 || penalty == 1), ARFLOW_EPARAM);
   namespace cw = census_warp;
-  const unsigned cb = af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B2);
-  const unsigned sb = (unsigned)af_cdiv(w2, 256) * (unsigned)h2 * (unsigned)B2;
   const SmoothArgs sa{flow2, img2, 3, h2, w2, flow2_bstride, flow_scale, alpha, order, wmode, penalty};
   hipStream_t st = (hipStream_t)stream;
+  if (use_col(true)) return census_col_pair_bwd_smooth(gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, radius, flow2, flow2_bstride, img2, h2, w2,
+                                                         flow_scale, alpha, order, wmode, penalty, coef2, gflow2, st);
+  const unsigned cb = af_grid_for_tiles((long)af_cdiv(W, cw::TXW) * af_cdiv(H, cw::TYH) * B2);
+  const unsigned sb = (unsigned)af_cdiv(w2, 256) * (unsigned)h2 * (unsigned)B2;
   switch (radius) {
     case 1: hipLaunchKernelGGL(cw::pair_bwd_smooth_kernel<1>, dim3(cb + sb), dim3(cw::NT), 0, st, gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, cb, sa, coef2, gflow2); break;
     case 2: hipLaunchKernelGGL(cw::pair_bwd_smooth_kernel<2>, dim3(cb + sb), dim3(cw::NT), 0, st, gray, flow, flow_bstride, dham, scale2, gflow, B2, H, W, cb, sa, coef2, gflow2); break;

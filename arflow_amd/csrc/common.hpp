@@ -106,15 +106,19 @@ int af_sums_rows(int B, int H, int W);  // api.hip: rows every `sums` buffer has
 // and bilinear taps -- over different L2s (measured: 2.6x fabric read over-fetch in the warp forward).
 // Give every XCD a contiguous run of tiles: id b runs tile (b % 8) * ceil(T/8) + b / 8.  Pure speed.
 // Returns false for the padding ids of the rounded-up grid (launch with af_grid_for_tiles(T) blocks).
-__device__ __forceinline__ bool af_tile_of_block(int ntx, int nty, int nimg, int& tx, int& ty, int& img) {
+// bx: the workgroup's index in the 1-D tile grid (blockIdx.x, or what a role-fused kernel derives from it).
+__device__ __forceinline__ bool af_tile_of_block(int ntx, int nty, int nimg, int& tx, int& ty, int& img, unsigned bx) {
   const int T = ntx * nty * nimg;
   const int per = (T + 7) >> 3;
-  const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || t >= T) return false;
+  const int t = (int)(bx & 7) * per + (int)(bx >> 3);
+  if ((int)(bx >> 3) >= per || t >= T) return false;
   tx = t % ntx;
   ty = (t / ntx) % nty;
   img = t / (ntx * nty);
   return true;
+}
+__device__ __forceinline__ bool af_tile_of_block(int ntx, int nty, int nimg, int& tx, int& ty, int& img) {
+  return af_tile_of_block(ntx, nty, nimg, tx, ty, img, blockIdx.x);
 }
 static inline unsigned af_grid_for_tiles(long T) { return 8u * (unsigned)((T + 7) / 8); }
 
@@ -130,17 +134,31 @@ __device__ __forceinline__ float af_unnormalize(float g, int size, bool align) {
 //   norm 1 (UFlow resample, utils/uflow_utils.py:71-76): g = 2*(p+u)/max(n_src-1,1) - 1, align=True;
 //   norm 2: as 1, but `u` is the absolute coordinate (resample(source, coords) called directly).
 // *dcoord receives d(coordinate)/d(u).
+// x / den for an INTEGER-valued divisor den >= 1 (the image extents minus one), bit-identical to the IEEE division
+// wherever the quotient matters: r = RN(1/den), q = RN(x r), q' = fma(fma(-q, den, x), r, q) -- 3 VALU instructions
+// instead of the ~11 of v_div_scale / v_rcp / 4 x v_fma / v_div_fmas / v_div_fixup (the reciprocal is wave-uniform), and
+// no branch (the IEEE sequence's special-case handling split every tile-fill loop into basic blocks).  Correctly rounded
+// by Markstein's theorem (r correctly rounded, q faithful, den's significand not all ones -- no integer below 2^24 - 1
+// is); tools/ubench/div_exact.hip checks EVERY float |x| <= 2^15 against EVERY divisor 1 .. 16384 on the GPU: 0
+// mismatches with |x / den| >= 1e-30.  Below that (signed zeros, denormal quotients: the residual underflows) the callers'
+// `- 1.0f` absorbs the quotient entirely.
+__device__ __forceinline__ float af_div_den(float x, float den) {
+  const float r = 1.0f / den;
+  const float q = x * r;
+  return fmaf(fmaf(-q, den, x), r, q);
+}
+
 __device__ __forceinline__ float af_sample_coord(float p, float u, int n_flow, int n_src, int norm,
                                                  bool align, float* dcoord) {
   if (norm != ARFLOW_NORM_ARFLOW) {
     const float den = (float)(n_src - 1 > 1 ? n_src - 1 : 1);
     const float pos = norm == ARFLOW_NORM_UFLOW_ABS ? u : p + u;  // ABS: `u` already is the coordinate
-    const float g = 2.0f * pos / den - 1.0f;
+    const float g = af_div_den(2.0f * pos, den) - 1.0f;
     *dcoord = (2.0f / den) * ((float)(n_src - 1) / 2.f);
     return ((g + 1.f) / 2.f) * (float)(n_src - 1);
   }
   const float den = (float)(n_flow - 1);
-  const float g = 2.0f * (p + u) / den - 1.0f;
+  const float g = (n_flow > 1 ? af_div_den(2.0f * (p + u), den) : 2.0f * (p + u) / den) - 1.0f;
   *dcoord = (2.0f / den) * (align ? (float)(n_src - 1) / 2.f : (float)n_src / 2.f);
   return af_unnormalize(g, n_src, align);
 }

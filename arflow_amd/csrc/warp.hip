@@ -595,14 +595,15 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
                                                          const float* __restrict__ flow, float* __restrict__ gflow,
                                                          int nimg, int C, int H, int W, long fbs, int pad, int align,
                                                          int norm, const float* __restrict__ add1, long add1_bs,
-                                                         const float* __restrict__ add2, const LevelBwdArgs& la) {
+                                                         const float* __restrict__ add2, const LevelBwdArgs& la,
+                                                         unsigned bx) {
   using namespace fwd_win;
   constexpr int CCH = 2;
   __shared__ __attribute__((aligned(16))) float win[CCH * HMAX * 72];
   __shared__ int red[4][4];
   __shared__ int box[4];
   int btx, bty, b;
-  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b)) return;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b, bx)) return;
   const int x = btx * TX + (int)(threadIdx.x & 31), y = bty * TY + (int)(threadIdx.x >> 5);
   const bool inside = x < W && y < H;
   const int Hs = H, Ws = W;
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256) void level_warp_bwd_flow_kernel(const float* _
                                                                   int nimg, int C, int H, int W, long fbs, int pad, int align,
                                                                   int norm, const float* __restrict__ add1, long add1_bs,
                                                                   const float* __restrict__ add2, LevelBwdArgs la) {
-  level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la);
+  level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la, blockIdx.x);
 }
 
 // Adjoint of the x2 bilinear flow upsample of the level forward (up2_source), times the factor 2 of
@@ -776,7 +777,8 @@ __device__ __forceinline__ void warp_bwd_src_body(const float* __restrict__ gout
                                                   int pad, int align, int norm,
                                                   const float* __restrict__ x2w,
                                                   const double* __restrict__ rows, int nrows,
-                                                  const float* __restrict__ stats, int mode, SlabArgs sl = SlabArgs{}) {
+                                                  const float* __restrict__ stats, int mode, unsigned bx,
+                                                  SlabArgs sl = SlabArgs{}) {
   // cell c lives at halfword cell_ptr[c + (c >> 5)]: the scan walks a lane-private run of consecutive cells,
   // and the +1-per-32 skew keeps 64 lanes with a stride that is a multiple of 32 off a common bank.
   // 16-bit cells (a workgroup has at most 4 * 256 = 1024 list entries) halve the array: 17 KB instead of
@@ -793,7 +795,7 @@ __device__ __forceinline__ void warp_bwd_src_body(const float* __restrict__ gout
   __shared__ int wave_tot[2][NT / 64];
   const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
   int btx, bty, b;
-  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b)) return;  // whole workgroup
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b, bx)) return;  // whole workgroup
   const int x = btx * TX + lx, y = bty * TY + ly;
   const bool inside = x < W && y < H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1007,7 +1009,8 @@ __global__ __launch_bounds__(NT) void warp_bwd_src_kernel(const float* __restric
                                                           const double* __restrict__ rows = nullptr, int nrows = 0,
                                                           const float* __restrict__ stats = nullptr, int mode = 0,
                                                           SlabArgs sl = SlabArgs{}) {
-  warp_bwd_src_body<NB, SLAB>(gout, flow, gsrc, nimg, C, Hs, Ws, H, W, fbs, pad, align, norm, x2w, rows, nrows, stats, mode, sl);
+  warp_bwd_src_body<NB, SLAB>(gout, flow, gsrc, nimg, C, Hs, Ws, H, W, fbs, pad, align, norm, x2w, rows, nrows, stats, mode,
+                              blockIdx.x, sl);
 }
 
 // Second pass of the SLAB form: one workgroup per 8 x 32 block of gsrc (x a channel split): the rectangles of the sample's
@@ -1076,9 +1079,11 @@ __global__ __launch_bounds__(NT) void slab_gather_kernel(const float* __restrict
 }
 }  // namespace lds_scatter
 
-// Coarse / middle pyramid levels: the two independent gradient kernels of the warp as ONE launch (blockIdx.z picks the
-// role), so that they overlap instead of paying two launch latencies back to back on a few hundred tiles.  (The fine
-// level keeps them apart: together they need 51 KB of LDS, 3 workgroups per CU instead of 4 and 8.)
+// The two independent gradient kernels of the warp as ONE launch.  The roles alternate in runs of 8 workgroups along
+// blockIdx.x (bit 3 picks the role; the low 3 bits -- the XCD a workgroup lands on -- and the tile index are those of the
+// plain kernels), so the two workgroups of a tile are dispatched next to each other on the SAME XCD: the second one finds
+// the tile's g2n in that L2, and the atomics-bound role runs beside the gather-bound one instead of after it (roles in
+// blockIdx.z were dispatched one after the other: the launch took the SUM of the two kernels' times).
 __global__ __launch_bounds__(256) void level_warp_bwd_both_kernel(const float* __restrict__ g2n, const float* __restrict__ src,
                                                                   const float* __restrict__ x2w,
                                                                   const float* __restrict__ flow, float* __restrict__ gsrc,
@@ -1086,11 +1091,12 @@ __global__ __launch_bounds__(256) void level_warp_bwd_both_kernel(const float* _
                                                                   long fbs, int pad, int align, int norm,
                                                                   const float* __restrict__ add1, long add1_bs,
                                                                   const float* __restrict__ add2, LevelBwdArgs la) {
-  if (blockIdx.z == 0)
+  const unsigned bx = (blockIdx.x & 7u) | ((blockIdx.x >> 4) << 3);
+  if ((blockIdx.x & 8u) == 0)
     lds_scatter::warp_bwd_src_body<true>(g2n, flow, gsrc, nimg, C, H, W, H, W, fbs, pad, align, norm, x2w, la.rows, la.nrows,
-                                         la.stats, la.mode);
+                                         la.stats, la.mode, bx);
   else
-    level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la);
+    level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la, bx);
 }
 
 // Forward splat of the 4 bilinear weights of every pixel's target position (compute_range_map /
@@ -1398,7 +1404,7 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
   // the atomic flush; it is bit-reproducible across workgroup scheduling, the atomics are not
   const bool want_slab = slab != nullptr && per <= lds_scatter::MAXT;
   if (tiles * nsplit <= 2048 && !want_slab) {  // both roles in one launch
-    hipLaunchKernelGGL(level_warp_bwd_both_kernel, dim3(grid.x, grid.y, 2), dim3(256), 0, st, g2n, x2, x2w, flow, gx2, gflow,
+    hipLaunchKernelGGL(level_warp_bwd_both_kernel, dim3(2 * grid.x, grid.y), dim3(256), 0, st, g2n, x2, x2w, flow, gx2, gflow,
                        B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
     return af_launch_status();
   }
