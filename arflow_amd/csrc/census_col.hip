@@ -19,6 +19,7 @@ __global__ __launch_bounds__(census_col::NT) void fwd_col_kernel(const float* __
   __shared__ float ta[cc::TILE];
   __shared__ float tb[cc::TILE];
   __shared__ float tm[cc::TILE];
+  __shared__ float tocc[cc::OCC_R * cc::OCC_P];
   __shared__ float red[2 * (cc::NT / 64)];
   int btx, bty, b;
   if (!af_tile_of_block(cc::tiles_x(W, R), cc::tiles_y(H), nimg, btx, bty, b)) {
@@ -28,8 +29,11 @@ __global__ __launch_bounds__(census_col::NT) void fwd_col_kernel(const float* __
   const int y0 = bty * cc::TROWS, x0 = btx * cc::Geo<R>::UX - R;
   const long cs = (long)H * W;
   const int bp = pair ? (b ^ 1) : b;
-  cc::fill_tiles<R, false>(ta, tb, tm, nullptr, nullptr, gray_a + b * cs, gray_b + bp * cs, flow + b * fbs,
-                           occ_small ? occ_small + (long)bp * (H / 4) * (W / 4) : nullptr, H, W, y0, x0);
+  const float* occ = occ_small ? occ_small + (long)bp * (H / 4) * (W / 4) : nullptr;
+  const int ox = max(x0 + R, 0);  // first owned column
+  if (occ) cc::stage_occ(tocc, occ, H / 4, W / 4, y0, ox);
+  cc::fill_tiles<R, false>(ta, tb, tm, nullptr, nullptr, gray_a + b * cs, gray_b + bp * cs, flow + b * fbs, nullptr, H, W, y0,
+                           x0);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float s[cc::K];
@@ -42,7 +46,8 @@ __global__ __launch_bounds__(census_col::NT) void fwd_col_kernel(const float* __
     for (int i = 0; i < cc::K; ++i) {
       const int y = y0 + w * cc::K + i;
       if (y < H) {
-        const float mv = tm[(R + w * cc::K + i) * cc::PITCH + lane];
+        float mv = tm[(R + w * cc::K + i) * cc::PITCH + lane];  // mask_invalid; x the upsampled range map
+        if (occ) mv *= cc::up4_lds(tocc, H / 4, W / 4, y0, ox, y, x);
         const float pm = (colin && y >= R && y < H - R) ? mv : 0.f;
         const float lg = __log2f(fabsf(s[i]) + 0.01f);
         part[0] += exp2f(0.4f * lg) * pm;

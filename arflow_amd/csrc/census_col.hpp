@@ -115,8 +115,8 @@ __device__ __forceinline__ void load_gray_warped(float* __restrict__ tile, const
 // taps per owned pixel: with every workgroup of the launch resident at once and in the same phase, that latency was not
 // hidden by anybody's arithmetic -- it ADDED 22 us to the 28 us pair loop at 8 x 384 x 640).
 //   ta: grey a;  tb: grey b warped by the position's flow (zero outside the image: the census transform zero-pads);
-//   forward  (BWD = false): t2 = mask = upsample(clamp(range map, 0, 1), x4) * mask_invalid(flow) at the position
-//                           (p2 = the range-map plane [H/4, W/4], nullable);
+//   forward  (BWD = false): t2 = mask_invalid(flow) at the position (utils/uflow_utils.py:35-50); the range-map factor of
+//                           the mask comes from stage_occ / up4_lds below;
 //   backward (BWD = true):  t2 = dham (p2, plain), t3 / t4 = d sample / d flow_x, _y of the warp at the position (the
 //                           bilinear corner differences of grey b -- the four taps are the sample's own).
 template <int R, bool BWD>
@@ -126,7 +126,6 @@ __device__ __forceinline__ void fill_tiles(float* __restrict__ ta, float* __rest
                                            const float* __restrict__ p2, int H, int W, int y0, int x0) {
   constexpr int NR = Geo<R>::NR, NC = Geo<R>::NC, ITER = (NR * NC + NT - 1) / NT, HB = (ITER + 1) / 2;
   const long cs = (long)H * W;
-  const int h4 = H / 4, w4 = W / 4;
 #pragma unroll
   for (int k0 = 0; k0 < ITER; k0 += HB) {
     float u[HB], v[HB], pa[HB], pg[HB];
@@ -145,7 +144,7 @@ __device__ __forceinline__ void fill_tiles(float* __restrict__ ta, float* __rest
       pa[k] = ga[o];
       pg[k] = BWD ? p2[o] : 0.f;
     }
-    float a[HB][4], oc[HB][4];
+    float a[HB][4];
     Taps t[HB];
     TapPlan p[HB];
 #pragma unroll
@@ -154,14 +153,6 @@ __device__ __forceinline__ void fill_tiles(float* __restrict__ ta, float* __rest
       p[k] = plan_taps(t[k], H, W);
 #pragma unroll
       for (int q = 0; q < 4; ++q) a[k][q] = gsrc[p[k].o[q]];
-      if (!BWD && p2) {  // the 4 range-map cells of up4_clamped (torch bilinear x4, align_corners=False)
-        const int yy = in[k] ? gy[k] : 0, xx = in[k] ? gx[k] : 0;
-        const float sy = fmaxf(0.25f * ((float)yy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.25f * ((float)xx + 0.5f) - 0.5f, 0.f);
-        const int ya = (int)sy, xa = (int)sx;
-        const int yb = ya + (ya < h4 - 1 ? 1 : 0), xb = xa + (xa < w4 - 1 ? 1 : 0);
-        oc[k][0] = p2[(long)ya * w4 + xa], oc[k][1] = p2[(long)ya * w4 + xb];
-        oc[k][2] = p2[(long)yb * w4 + xa], oc[k][3] = p2[(long)yb * w4 + xb];
-      }
     }
 #pragma unroll
     for (int k = 0; k < HB; ++k) {
@@ -180,19 +171,39 @@ __device__ __forceinline__ void fill_tiles(float* __restrict__ ta, float* __rest
         } else {
           // mask_invalid(flow_to_warp(flow)), utils/uflow_utils.py:35-50 (as warp_fwd_kernel's `valid`)
           const float cx = (float)gx[k] + u[k], cy = (float)gy[k] + v[k];
-          float mv = (cx >= 0.f && cx <= (float)(W - 1) && cy >= 0.f && cy <= (float)(H - 1)) ? 1.f : 0.f;
-          if (p2) {  // x upsample(clamp(range map, 0, 1), x4): the arithmetic of up4_clamped
-            const float sy = fmaxf(0.25f * ((float)gy[k] + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.25f * ((float)gx[k] + 0.5f) - 0.5f, 0.f);
-            const float ly = sy - (float)(int)sy, lx = sx - (float)(int)sx;
-            auto cl = [](float z) { return fminf(fmaxf(z, 0.f), 1.f); };
-            mv *= (1.f - ly) * ((1.f - lx) * cl(oc[k][0]) + lx * cl(oc[k][1])) +
-                  ly * ((1.f - lx) * cl(oc[k][2]) + lx * cl(oc[k][3]));
-          }
+          const float mv = (cx >= 0.f && cx <= (float)(W - 1) && cy >= 0.f && cy <= (float)(H - 1)) ? 1.f : 0.f;
           t2[o] = in[k] ? mv : 0.f;
         }
       }
     }
   }
+}
+
+// upsample(clamp(range map, 0, 1), x4) for the tile's owned pixels out of LDS: the <= OCC_R x OCC_C cells of the [H/4, W/4]
+// range map under the tile are staged once per workgroup, already clamped (one load per thread instead of 4 gathers per
+// pixel), and up4_lds applies torch's bilinear arithmetic (align_corners=False, as up4_clamped) to them.
+constexpr int OCC_R = TROWS / 4 + 2, OCC_C = 64 / 4 + 3, OCC_P = OCC_C + 1;
+__device__ __forceinline__ int up4_first(int p) {  // first source cell of output index p (>= 0)
+  return (int)fmaxf(0.25f * ((float)p + 0.5f) - 0.5f, 0.f);
+}
+__device__ __forceinline__ void stage_occ(float* __restrict__ tocc, const float* __restrict__ occ, int h4, int w4, int y0,
+                                          int x0) {  // y0, x0: first OWNED row / column of the tile (>= 0)
+  const int oy0 = up4_first(y0), ox0 = up4_first(x0);
+  for (int i = threadIdx.x; i < OCC_R * OCC_P; i += NT) {
+    const int r = i / OCC_P, c = i - r * OCC_P;
+    const float v = occ[(long)min(oy0 + r, h4 - 1) * w4 + min(ox0 + c, w4 - 1)];
+    tocc[i] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
+__device__ __forceinline__ float up4_lds(const float* __restrict__ tocc, int h4, int w4, int y0, int x0, int y, int x) {
+  const float sy = fmaxf(0.25f * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.25f * ((float)x + 0.5f) - 0.5f, 0.f);
+  const int ya = (int)sy, xa = (int)sx;
+  const int yb = ya + (ya < h4 - 1 ? 1 : 0), xb = xa + (xa < w4 - 1 ? 1 : 0);
+  const float ly = sy - (float)ya, lx = sx - (float)xa;
+  const int oy0 = up4_first(y0), ox0 = up4_first(x0);
+  const float v00 = tocc[(ya - oy0) * OCC_P + xa - ox0], v01 = tocc[(ya - oy0) * OCC_P + xb - ox0];
+  const float v10 = tocc[(yb - oy0) * OCC_P + xa - ox0], v11 = tocc[(yb - oy0) * OCC_P + xb - ox0];
+  return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
 // column `col` of a tile, rows [row0, row0 + K + 2R) -> registers
