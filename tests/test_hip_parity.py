@@ -599,16 +599,19 @@ def test_random_shapes_fuzz(AF, oracle):
             assert_close(gsc, gsr, (1e-6 + 1e-5 * float(gsr.abs().max())) / 100, 1e-6, tag + ' smooth grad')
 
 
-@pytest.mark.parametrize('sym', ['0', '1'], ids=['ordered', 'pair-symmetric'])
+@pytest.mark.parametrize('family', ['column', 'ordered', 'pair-symmetric'])
 @pytest.mark.parametrize('size', [(2, 48, 64), (1, 16, 64), (3, 40, 132), (2, 96, 160), (1, 100, 236)],
                          ids=lambda s: 'x'.join(map(str, s)))
-def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, sym, monkeypatch):
+def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, family, monkeypatch):
     """arflow_census_warp_fwd/bwd (warp + validity + x4 mask upsample + census loss in one launch each way, on the
     grey planes of arflow_down4_gray) against the three separate launches it replaces and against the oracle's
     composition of the reference functions (losses/uflow_loss.py:30-54): mask bit-identical, loss and flow
     gradient at the census tolerances (grey-then-sample re-associates fp32 sums)."""
     from arflow_amd import uflow_utils as U
-    monkeypatch.setenv('ARFLOW_CENSUS_SYM', sym)  # read by the library at every call: both kernel families are tested
+    # read by the library at every call: all three kernel families are tested (column = the default, census_col.hip; ordered
+    # = the 4-pixels-per-lane kernels of census_warp.hip; pair-symmetric = census_sym.hip)
+    monkeypatch.setenv('ARFLOW_CENSUS_SYM', '1' if family == 'pair-symmetric' else '0')
+    monkeypatch.setenv('ARFLOW_CENSUS_COL', '0' if family == 'ordered' else '1')
     B, H, W = size
     gen = torch.Generator().manual_seed(H + W)
     im1, im2 = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, 3, H, W, generator=gen)
@@ -806,9 +809,12 @@ def test_general_correlation_parameters(oracle, cfg):
         assert_close(y, oracle.correlation(x1, x2, 4), 1e-6, 1e-5, 'default == correlation_native')
 
 
-def test_uflow_loss_both_directions_in_one_pass_equals_sequential():
+@pytest.mark.parametrize('family', ['column', 'ordered'])
+def test_uflow_loss_both_directions_in_one_pass_equals_sequential(family, monkeypatch):
     """UFlowLoss with_bk: the one-pass form over 2B (image pair, direction) samples (arflow_census_warp_pair_*) against the
-    per-direction form (the reference's order, losses/uflow_loss.py:30-54): same losses, mask and flow gradients."""
+    per-direction form (the reference's order, losses/uflow_loss.py:30-54): same losses, mask and flow gradients; with the
+    pair-shared column kernels (census_col.hip, the default) and with the ordered-pair kernels (census_warp.hip)."""
+    monkeypatch.setenv('ARFLOW_CENSUS_COL', '0' if family == 'ordered' else '1')
     from arflow_amd.config import AttrDict
     from arflow_amd.losses import UFlowLoss
     from oracle.fixture_common import synth_pair

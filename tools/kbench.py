@@ -131,7 +131,21 @@ def main():
                                      gbuf[:, 81 + C:].data_ptr() if has_flow else None, bs, p(gext) if has_flow else None,
                                      p(lstats), 0, p(g1), p(g2), p(gfc) if has_flow else None, int(has_flow), 1, p(ws), B2, C, h,
                                      w, 4, 0.1, 0, 1, 0, s)
+            # the form the models call (arflow_level_fwd_m): the maps' moments come from the conv epilogue that produced them
+            mrows = lib.arflow_bias_act_mom_rows(C, h * w)
+            bias0 = torch.zeros(C, device=dev)
+            r1 = torch.empty(B2, mrows, 2, device=dev, dtype=torch.float64)
+            r2 = torch.empty(B2, mrows, 2, device=dev, dtype=torch.float64)
+            lib.arflow_bias_act_fwd_mom(p(x1), p(bias0), p(x1), p(r1), B2, C, h * w, 1.0, s)  # slope 1, bias 0: x unchanged
+            lib.arflow_bias_act_fwd_mom(p(x2), p(bias0), p(x2), p(r2), B2, C, h * w, 1.0, s)
+
+            def lfwd_m():
+                lib.arflow_level_fwd_m(p(x1), p(x2), p(fc), 2 * (h // 2) * (w // 2), int(has_flow), 1, p(fup) if has_flow else None,
+                                       fslot.data_ptr() if has_flow else None, bs, p(x2w) if has_flow else None, 0, vol.data_ptr(), bs,
+                                       x1n.data_ptr(), bs, p(lsign), p(lstats), p(lacc), p(r1), mrows, None if has_flow else p(r2),
+                                       0 if has_flow else mrows, B2, C, h, w, 4, 0.1, 0, 1, 0, s)
             rec('arflow_level_fwd', (B2, C, h, w, 4, 3, fk), timeit(lfwd, args.iters))
+            rec('arflow_level_fwd_m', (B2, C, h, w, 4, 3, fk, 1), timeit(lfwd_m, args.iters))
             rec('arflow_level_bwd', (B2, C, h, w, 4, 3, fk), timeit(lbwd, args.iters))
     # loss side: B = batch/2 image pairs at full resolution, per direction
     B = max(1, B2 // 2)
@@ -170,6 +184,26 @@ def main():
         rec('arflow_census_warp_bwd', (B, H0, W0, 'smooth'), timeit(lambda: lib.arflow_census_warp_bwd(p(gr1), p(gr2), p(fls), 2 * H0 * W0, p(dham), p(one), p(gfl0), B, H0, W0, 3, s), args.iters))
         rec('arflow_census_warp_fwd', (B, H0, W0), timeit(lambda: lib.arflow_census_warp_fwd(p(gr1), p(gr2), p(fl0), 2 * H0 * W0, p(occ), p(maskw), p(dham), p(sums), B, H0, W0, 3, s), args.iters))
         rec('arflow_census_warp_bwd', (B, H0, W0), timeit(lambda: lib.arflow_census_warp_bwd(p(gr1), p(gr2), p(fl0), 2 * H0 * W0, p(dham), p(one), p(gfl0), B, H0, W0, 3, s), args.iters))
+    if want('pair'):  # UFlowLoss as bench.py runs it: both directions as ONE batch of 2B = --batch samples (sample s = 2 b + direction)
+        B2p = B2
+        imgs = torch.rand(B2p, 3, H0, W0, device=dev, generator=g)
+        smallp = torch.empty(B2p, 3, H0 // 4, W0 // 4, device=dev)
+        grayp = torch.empty(B2p, 1, H0, W0, device=dev)
+        occp = torch.empty(B2p, 1, H0 // 4, W0 // 4, device=dev)
+        fl2p = 1.0 * torch.randn(B2p, 2, H0 // 4, W0 // 4, device=dev, generator=g)
+        fl0p = torch.nn.functional.interpolate(fl2p * 4, scale_factor=4, mode='bilinear', align_corners=False).contiguous()
+        dhamp = torch.empty(B2p, 1, H0, W0, device=dev)
+        maskp = torch.empty(B2p, 1, H0, W0, device=dev)
+        sump = torch.empty(4 * lib.arflow_sums_rows(B2p, H0, W0), device=dev)
+        sums2 = torch.empty(4 * lib.arflow_sums_rows(B2p, H0 // 4, W0 // 4), device=dev)
+        gf0p, gf2p = torch.empty_like(fl0p), torch.empty_like(fl2p)
+        sc2, cf2 = torch.ones(2, device=dev), torch.ones(2, device=dev)
+        h4, w4 = H0 // 4, W0 // 4
+        rec('arflow_down4_gray_z', (B2p, H0, W0), timeit(lambda: lib.arflow_down4_gray_z(p(imgs), p(smallp), p(grayp), p(occp), B2p, H0, W0, s), args.iters))
+        # (the range map keeps accumulating over the timed calls -- it is cleared by arflow_down4_gray_z in a step; same work)
+        rec('arflow_splat_smooth_fwd', (B2p, 3, h4, w4), timeit(lambda: lib.arflow_splat_smooth_fwd(p(fl2p), p(smallp), p(occp), p(sums2), B2p, h4, w4, 2 * h4 * w4, 1.0, 150.0, 1, 1, 1, 1, s), args.iters))
+        rec('arflow_census_warp_pair_fwd', (B2p, H0, W0), timeit(lambda: lib.arflow_census_warp_pair_fwd(p(grayp), p(fl0p), 2 * H0 * W0, p(occp), p(maskp), p(dhamp), p(sump), B2p, H0, W0, 3, s), args.iters))
+        rec('arflow_uflow_pair_bwd', (B2p, H0, W0), timeit(lambda: lib.arflow_uflow_pair_bwd(p(grayp), p(fl0p), 2 * H0 * W0, p(dhamp), p(sc2), p(gf0p), B2p, H0, W0, 3, p(fl2p), 2 * h4 * w4, p(smallp), p(cf2), p(gf2p), h4, w4, 1.0, 150.0, 1, 1, 1, s), args.iters))
     if want('photo_fwd'):
         rec('arflow_photo_fwd', (B, 3, H0, W0), timeit(lambda: lib.arflow_photo_fwd(p(im1), p(im2), p(mask), None, p(sums), B, 3, H0, W0, s), args.iters))
     if want('photo_bwd'):
