@@ -78,7 +78,7 @@ PROTOTYPES = {
     'arflow_up4_clamp_mul': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 

@@ -3,7 +3,7 @@
 #include <atomic>
 #include <cstdio>
 
-extern "C" int arflow_abi_version(void) { return 9; }
+extern "C" int arflow_abi_version(void) { return 10; }
 
 // A HIP error that was already pending on the calling thread when an entry point was entered (left behind by
 // the framework or by an earlier, unchecked call).  Kept, not dropped: first one is reported once on stderr.

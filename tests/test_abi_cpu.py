@@ -50,7 +50,7 @@ def test_prototype_arity_matches_header():
 
 def test_argument_errors_without_gpu(lib):
     # validation happens before any launch, so these are safe on a CPU-only host
-    assert lib.arflow_abi_version() == 9
+    assert lib.arflow_abi_version() == 10
     assert lib.arflow_corr_fwd(None, None, None, None, 1, 1, 1, 1, 4, 1.0, None) == -1001
     one = ctypes.c_void_p(16)
     assert lib.arflow_corr_fwd(one, one, one, None, 0, 1, 1, 1, 4, 1.0, None) == -1002

@@ -55,6 +55,16 @@ __global__ __launch_bounds__(256) void k(float* __restrict__ dst, int ntile_x, i
         const int r = i / BW, cx = i - r * BW;
         atomicAdd(d + (long)(y0 + r) * W + x0 + cx, 1.0f);
       }
+    } else if (MODE == 7 || MODE == 8) {  // shape 0 with WORKGROUP / WAVEFRONT-scope atomics: executed in the XCD's L2 instead of memory-side
+      // (NOT coherent across XCDs: a throughput probe only -- what an L2-local accumulation could run at)
+      for (int i = threadIdx.x; i < BH * BW; i += 256) {
+        const int r = i / BW, cx = i - r * BW;
+        float* d = base + (long)c0 * plane + (long)(y0 + r) * W + x0 + cx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          __hip_atomic_fetch_add(d + c * plane, 1.0f, __ATOMIC_RELAXED,
+                                 MODE == 7 ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     } else if (MODE == 6) {  // plain stores in shape 5 (what the bytes cost without the atomic unit)
       float* d = base + (long)(c0 + wave) * plane;
       for (int i = lane; i < BH * BW; i += 64) {
@@ -93,5 +103,7 @@ int main() {
   run<4>("4 dense aligned 256-B instructions (reference)", dst);
   run<5>("5 compacted cells, lane-strided, wave = channel", dst);
   run<6>("6 plain stores, shape 5", dst);
+  run<7>("7 shape 0, workgroup-scope atomics (L2-local; probe only)", dst);
+  run<8>("8 shape 0, wavefront-scope atomics (probe only)", dst);
   return 0;
 }
