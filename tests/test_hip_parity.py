@@ -809,12 +809,12 @@ def test_general_correlation_parameters(oracle, cfg):
         assert_close(y, oracle.correlation(x1, x2, 4), 1e-6, 1e-5, 'default == correlation_native')
 
 
-@pytest.mark.parametrize('family', ['column', 'ordered'])
+@pytest.mark.parametrize('family', ['column', 'ordered', 'column-forward-only'])
 def test_uflow_loss_both_directions_in_one_pass_equals_sequential(family, monkeypatch):
     """UFlowLoss with_bk: the one-pass form over 2B (image pair, direction) samples (arflow_census_warp_pair_*) against the
     per-direction form (the reference's order, losses/uflow_loss.py:30-54): same losses, mask and flow gradients; with the
     pair-shared column kernels (census_col.hip, the default) and with the ordered-pair kernels (census_warp.hip)."""
-    monkeypatch.setenv('ARFLOW_CENSUS_COL', '0' if family == 'ordered' else '1')
+    monkeypatch.setenv('ARFLOW_CENSUS_COL', {'ordered': '0', 'column': '1', 'column-forward-only': 'f'}[family])
     from arflow_amd.config import AttrDict
     from arflow_amd.losses import UFlowLoss
     from oracle.fixture_common import synth_pair
