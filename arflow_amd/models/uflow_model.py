@@ -46,17 +46,26 @@ class PWCFeaturePyramid(nn.Module):
                 c = 32
             self._convs.append(group)
 
+    pyramid_moments = None  # per level: [B, rows, 2] partial (sum, sum of squares) of that level's map, or None
+
     def forward(self, x):
         x = x * 2. - 1.
-        features = []
+        features, moms = [], []
         for group in self._convs:
-            for conv in group:
+            mom = None
+            for i, conv in enumerate(group):
                 # the reference zero-pads by 1 explicitly and convolves 'valid' (models/uflow_model.py:453-457):
                 # the same numbers as padding=1 inside the convolution, without the padded copy;
                 # bias-free conv + fused bias / LeakyReLU pass
-                x = blocks.bias_act(func.conv2d(x, conv.weight, None, conv.stride, 1, conv.dilation),
-                                    conv.bias, self._leaky_relu_alpha)
+                y = func.conv2d(x, conv.weight, None, conv.stride, 1, conv.dilation)
+                if i == len(group) - 1 and y.is_cuda and blocks.bias_act is AF.bias_leaky_relu:
+                    # the conv that OUTPUTS a pyramid level: its epilogue also leaves normalize_features' sums of that map
+                    x, mom = AF.bias_leaky_relu_moments(y, conv.bias, self._leaky_relu_alpha)
+                else:
+                    x = blocks.bias_act(y, conv.bias, self._leaky_relu_alpha)
             features.append(x)
+            moms.append(mom)
+        self.pyramid_moments = moms
         return features
 
 
@@ -112,8 +121,9 @@ class PWCFlow(nn.Module):
         t = torch.tensor(vals, dtype=torch.float32).repeat_interleave(batch_per_pass, dim=0).t().contiguous()
         return t.to(device, non_blocking=True).view(n, -1, 1, 1, 1)
 
-    def forward_2_frames(self, feature_pyramid1, feature_pyramid2, drops=None):
-        """models/uflow_model.py:138-245."""
+    def forward_2_frames(self, feature_pyramid1, feature_pyramid2, drops=None, moments=None):
+        """models/uflow_model.py:138-245.  moments: optional (rows of the first maps, rows of the second maps) per pyramid
+        level -- the feature maps' partial moments from the extractor's conv epilogues (PWCFeaturePyramid.pyramid_moments)."""
         context = flow = flow_up = context_up = None
         flows = []
         k = 0
@@ -124,13 +134,15 @@ class PWCFlow(nn.Module):
             if fused:
                 # the whole level in front of the flow layers as one call: x2 flow upsample
                 # (uflow_utils.upsample: align_corners=False), resample, normalisation, cost volume + LeakyReLU
+                r1 = moments[0][level] if moments is not None else None
+                r2 = moments[1][level] if moments is not None else None
                 if level == top:
                     cfg = AF.LevelCfg(['vol', 0], 'avg', self._leaky_relu_alpha, 4)
-                    x_in = AF.level(features1, features2, None, cfg, features1)
+                    x_in = AF.level(features1, features2, None, cfg, features1, x1_rows=r1, x2_rows=r2)
                 else:
                     cfg = AF.LevelCfg([0, 'flow', 'vol', 1], 'avg', self._leaky_relu_alpha, 4, True, False, 'zeros', True,
                                       AF.NORM_UFLOW)
-                    x_in, flow_up = AF.level(features1, features2, flow, cfg, context_up, features1)
+                    x_in, flow_up = AF.level(features1, features2, flow, cfg, context_up, features1, x1_rows=r1)
             else:
                 if level != top:
                     flow_up = uflow_utils.upsample(flow, is_flow=True)
@@ -182,14 +194,21 @@ class PWCFlow(nn.Module):
             raise NotImplementedError
         B = x.size(0)
         pyr_all = self._feature_pyramid_extractor(torch.cat([x[:, 0:3], x[:, 3:6]], 0))
+        moms = self._feature_pyramid_extractor.pyramid_moments
+        have_m = moms is not None and all(t is not None for t in moms)
         p1 = [p[:B] for p in pyr_all]
         p2 = [p[B:] for p in pyr_all]
         res = {}
         if with_bk:
-            a, b = pair_batches(p1, p2)
-            flows = self.forward_2_frames(a, b, self._drops(2, B, x.device))
+            # first maps of the 2B (fw; bw) samples = the extractor's batch as it stands (no copy), second maps = its two
+            # halves swapped; the same holds for the rows of partial moments
+            a = list(pyr_all)
+            b = [torch.cat([p[B:], p[:B]], 0) for p in pyr_all]
+            m = (list(moms), [torch.roll(t, B, 0) for t in moms]) if have_m else None
+            flows = self.forward_2_frames(a, b, self._drops(2, B, x.device), m)
             res['flows_fw'] = [f[:B] for f in flows]
             res['flows_bw'] = [f[B:] for f in flows]
         else:
-            res['flows_fw'] = self.forward_2_frames(p1, p2, self._drops(1, B, x.device))
+            m = ([t[:B] for t in moms], [t[B:] for t in moms]) if have_m else None
+            res['flows_fw'] = self.forward_2_frames(p1, p2, self._drops(1, B, x.device), m)
         return res
