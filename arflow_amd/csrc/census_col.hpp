@@ -242,7 +242,7 @@ __device__ __forceinline__ float pair_dist(float ac, float bc, float an, float b
   const float da = an - ac, db = bn - bc;
   const float tb = db * __builtin_amdgcn_rsqf(fmaf(db, db, 0.81f));
   const float e = fmaf(da, __builtin_amdgcn_rsqf(fmaf(da, da, 0.81f)), -tb), sq = e * e;
-  return sq * __builtin_amdgcn_rcpf(0.1f + sq);
+  return sq * __builtin_amdgcn_rcpf(0.1f + sq);  // (folding this product into the two accumulations as FMAs: forward 81 -> 84 us)
 }
 // its derivative w.r.t. the warped grey value of the FIRST pixel (before the constant 0.1 * -2 * 0.81), as
 // census_warp::bwd_body evaluates it; odd under exchange of the two pixels
@@ -252,7 +252,8 @@ __device__ __forceinline__ float pair_grad(float ac, float bc, float an, float b
   const float ub = __builtin_amdgcn_rsqf(fmaf(db, db, 0.81f));
   const float e = fmaf(da, ua, -(db * ub));
   const float q = __builtin_amdgcn_rcpf(fmaf(e, e, 0.1f));
-  return ((q * e) * q) * ((ub * ub) * ub);
+  const float w = q * ub;  // q^2 e ub^3 = (q ub)^2 (e ub): 4 multiplications instead of 5
+  return (w * w) * (e * ub);
 }
 
 // Sum over the (2R+1)^2 - 1 neighbours of every pixel of the lane's K-row strip: s[i] = sum_o dist(pixel i, pixel i + o).
@@ -331,9 +332,9 @@ __device__ __forceinline__ void pair_sums_bwd(const float* __restrict__ ta, cons
         const int j = i + dy;
         const bool own = i >= 0 && i < K, oth = j >= 0 && j < K;
         if (j < -R || j >= K + R || !(own || oth)) continue;
-        const float v = (gc[i + R] + gn[j + R]) * pair_grad(ac[i + R], bc[i + R], an[j + R], bn[j + R]);
-        if (own) acc[i] += v;
-        if (oth) T[j] -= v;
+        const float gs = gc[i + R] + gn[j + R], hd = pair_grad(ac[i + R], bc[i + R], an[j + R], bn[j + R]);
+        if (own) acc[i] = fmaf(gs, hd, acc[i]);
+        if (oth) T[j] = fmaf(-gs, hd, T[j]);
         if (((i + R) & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // <= 4 evaluations interleaved (VGPRs: 203 -> 3 waves/SIMD)
       }
       pin(acc);
@@ -351,9 +352,9 @@ __device__ __forceinline__ void pair_sums_bwd(const float* __restrict__ ta, cons
       const int j = i + dy;
       const bool own = i >= 0, oth = j >= 0 && j < K;
       if (!(own || oth)) continue;
-      const float v = (gc[i + R] + gc[j + R]) * pair_grad(ac[i + R], bc[i + R], ac[j + R], bc[j + R]);
-      if (own) acc[i] += v;
-      if (oth) acc[j] -= v;
+      const float gs = gc[i + R] + gc[j + R], hd = pair_grad(ac[i + R], bc[i + R], ac[j + R], bc[j + R]);
+      if (own) acc[i] = fmaf(gs, hd, acc[i]);
+      if (oth) acc[j] = fmaf(-gs, hd, acc[j]);
       if (((i + R) & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     pin(acc);
