@@ -10,7 +10,10 @@ per = defaultdict(list)
 for r in rows:
     per[r['test']].append(r)
 out = {'_meta': {'commit': sys.argv[3] if len(sys.argv) > 3 else None,
-                 'what': 'per test: the assert_close() call with the largest err/tol; err_over_tol = 1 is the tolerance itself'}}
+                 'what': 'per test: the assert_close() call with the largest err/tol; err_over_tol = 1 is the tolerance itself',
+                 'note': 'tests left with more than 20x headroom compare at an absolute tolerance that is already at or below '
+                         'the SURVEY 8(a) figure (1e-6 .. 5e-6 on O(1) values: the measured error there is 1-8 ulp) or are '
+                         'bit-identical (max_err 0); dividing those further would only test the rounding of one box'}}
 for t, rs in sorted(per.items()):
     w = max(rs, key=lambda r: r['err_over_tol'])
     out[t] = {'worst': w['what'], 'err_over_tol': w['err_over_tol'], 'max_err': w['max_err'], 'atol': w['atol'], 'rtol': w['rtol'],
