@@ -21,6 +21,7 @@ python3 tools/pmc_calls.py valu $O/manifest_valu.json $O/pmc_valu/v_counter_coll
 python3 tools/level_bench.py > $O/level_bench.log 2>&1 || exit 1
 python3 tools/kbench_cold.py > $O/kbench_cold.log 2>&1 || exit 1
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value tools/ubench/div_exact.hip -o /tmp/div_exact 2>/dev/null && timeout -k 10 300 /tmp/div_exact 16384 > $O/div_exact.log 2>&1 || exit 1
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/ubench/atomic_shape.hip -o /tmp/atomic_shape 2>/dev/null && timeout -k 10 120 /tmp/atomic_shape > $O/atomic_shape.log 2>&1 || exit 1
 for w in "pwclite+unflow_loss 384 640 8" "pwclite_uflow+uflow_loss 448 1024 4" "pwcflow+uflow_loss 256 448 8" "pwclite3+mv_loss 384 640 8"; do
   set -- $w
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $1 --size $2 $3 --batch $4 2>/dev/null | tail -1 >> $O/bench_other_configs.jsonl || exit 1
