@@ -651,6 +651,36 @@ def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, family, 
     assert torch.equal(mask3, valid)
 
 
+@pytest.mark.parametrize('family', ['column', 'ordered'])
+@pytest.mark.parametrize('patch', [3, 5])
+def test_fused_census_warp_small_patches_vs_oracle(AF, oracle, patch, family, monkeypatch):
+    """The fused photometric direction with the census patch sizes no shipped config uses (radius 1 and 2: the other
+    instantiations of census_warp / census_col) against the oracle's composition of the reference functions
+    (utils/uflow_utils.py:241-293 with patch_size)."""
+    monkeypatch.setenv('ARFLOW_CENSUS_SYM', '0')
+    monkeypatch.setenv('ARFLOW_CENSUS_COL', '0' if family == 'ordered' else '1')
+    B, H, W = 2, 40, 132
+    gen = torch.Generator().manual_seed(patch)
+    im1, im2 = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, 3, H, W, generator=gen)
+    flow = 3.0 * torch.randn(B, 2, H, W, generator=gen)
+    flow[:, :, :2] += 20.0
+    occ = 1.6 * torch.rand(B, 1, H // 4, W // 4, generator=gen) - 0.2
+    _, gray1 = AF.down4_gray(cu(im1))
+    _, gray2 = AF.down4_gray(cu(im2), want_small=False)
+    f2 = cu(flow).requires_grad_(True)
+    l2, mask2 = AF.census_warp_loss(gray1, gray2, f2, cu(occ), patch)
+    g2, = torch.autograd.grad(l2, [f2])
+    fr = flow.clone().requires_grad_(True)
+    coords = oracle.flow_to_warp(fr)
+    rmask = torch.nn.functional.interpolate(occ.clamp(0, 1), scale_factor=4, mode='bilinear', align_corners=False) * \
+        oracle.mask_invalid(coords)
+    lr = oracle.census_loss(im1, oracle.resample(im2, coords), rmask.detach(), patch)
+    gr, = torch.autograd.grad(lr, [fr])
+    assert_close(mask2, rmask, 1e-6, 1e-6, 'mask vs oracle')
+    assert_close(l2, lr, 5e-7, 5e-6, 'loss vs oracle')
+    assert_close(g2, gr, 1e-6 + 1e-4 * float(gr.abs().max()), 1e-3, 'flow gradient vs oracle')
+
+
 @pytest.mark.parametrize('shape,slope', [((2, 32, 24, 40), 0.1), ((2, 8, 20, 36), 1.0), ((3, 32, 12, 20), 0.1), ((1, 5, 9, 11), 0.1)],
                          ids=lambda v: str(v))
 def test_correlation_concat_equals_cat_of_plain_op(AF, oracle, shape, slope):
