@@ -45,6 +45,7 @@ PROTOTYPES = {
     'arflow_level_fwd': [c_fp, c_fp, c_fp, c_l, c_i, c_i, c_fp, c_fp, c_l, c_fp, c_i, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_fp],
     'arflow_level_bwd': [c_fp, c_l, c_fp, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_fp, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_fp],
     'arflow_level_fwd_m': [c_fp, c_fp, c_fp, c_l, c_i, c_i, c_fp, c_fp, c_l, c_fp, c_i, c_fp, c_l, c_fp, c_l, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_fp],
+    'arflow_up2_bwd': [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp],
     'arflow_bias_act_mom_rows': [c_i, c_l],
     'arflow_bias_act_fwd_mom': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_l, c_f, c_fp],
     'arflow_level_acc_rows': [c_i, c_i, c_i, c_i, c_i],

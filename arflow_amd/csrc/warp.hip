@@ -1436,6 +1436,17 @@ int af_up2_bwd_launch(const float* gfine, float* gcoarse, int planes, int H, int
   return af_launch_status();
 }
 
+// Adjoint of `flow_up = interpolate(flow * 2, x2, bilinear)` as arflow_level_warp_fwd evaluates it (gather form, no
+// atomics, gcoarse fully written): gfine [B,2,H,W] -> gcoarse [B,2,H/2,W/2].  models/pwclite.py:178-179 backward.
+extern "C" int arflow_up2_bwd(const float* gfine, float* gcoarse, int B, int H, int W, int up_align_corners,
+                              arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gfine);
+  AF_REQUIRE_PTR(gcoarse);
+  AF_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && B <= 65535, ARFLOW_ESHAPE);
+  return af_up2_bwd_launch(gfine, gcoarse, B * 2, H, W, up_align_corners, (hipStream_t)stream);
+}
+
 extern "C" int arflow_warp_bwd(const float* gout, const float* src, const float* flow, float* gsrc,
                                float* gflow, int B, int C, int Hs, int Ws, int H, int W, long flow_bstride,
                                int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream) {

@@ -658,6 +658,70 @@ class WarpFunction(torch.autograd.Function):
         return gsrc, gflow, None, None, None, None
 
 
+class WarpUp2Function(torch.autograd.Function):
+    """The front of a PWC pyramid level as the ARFlow model writes it (models/pwclite.py:178-180):
+
+        flow_up = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=up_align)
+        out     = flow_warp(src, flow_up)
+
+    as ONE launch (arflow_level_warp_fwd: the upsample is evaluated in front of the warp's coordinate computation; the
+    upsampled flow is still written once -- the estimator and the residual sum read it).  Backward: arflow_warp_bwd (both
+    gradients w.r.t. the full-resolution flow) + arflow_up2_bwd (the upsample's adjoint as a gather).  Returns
+    (out, flow_up)."""
+
+    @staticmethod
+    def forward(ctx, src, flow, pad, align_corners, norm, up_align):
+        _need_gpu(src, flow)
+        src = src.contiguous()
+        flow, fbs = _flow_view(flow)
+        B, C, H, W = src.shape
+        if tuple(flow.shape) != (B, 2, H // 2, W // 2) or H % 2 or W % 2:
+            raise ValueError('warp_up2 needs a [B,2,H/2,W/2] flow for a [B,C,H,W] source with even H, W')
+        lib = _lib.load()
+        out = torch.empty_like(src)
+        flow_up = torch.empty(B, 2, H, W, device=src.device, dtype=torch.float32)
+        acc = torch.empty(4 * B * lib.arflow_level_acc_rows(B, C, H, W, 1), device=src.device, dtype=torch.float64)  # (moments: unused)
+        with torch.cuda.device_of(src):
+            _call('arflow_level_warp_fwd', None, _p(src), _p(flow), fbs, 1, int(bool(up_align)), _p(flow_up), None, 0, _p(out),
+                  _p(acc), B, C, H, W, pad, int(bool(align_corners)), norm, _stream(), key=(B, C, H, W, 1))
+        ctx.save_for_backward(src, flow_up)
+        ctx.cfg = (pad, int(bool(align_corners)), norm, int(bool(up_align)))
+        return out, flow_up
+
+    @staticmethod
+    def backward(ctx, gout, gflow_up):
+        src, flow_up = ctx.saved_tensors
+        pad, ac, norm, up_align = ctx.cfg
+        B, C, H, W = src.shape
+        gout = gout.contiguous()
+        gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        gcoarse = None
+        with torch.cuda.device_of(src):
+            if ctx.needs_input_grad[1]:
+                gfull = torch.empty(B, 2, H, W, device=src.device, dtype=torch.float32)
+                _call('arflow_warp_bwd', _p(gout), _p(src), _p(flow_up), _p(gsrc), _p(gfull), B, C, H, W, H, W, 2 * H * W, pad, ac,
+                      norm, _stream(), key=(B, C, H, W, gsrc is not None))
+                if gflow_up is not None:
+                    gfull = gfull + gflow_up  # what the estimator and the residual sum sent to the upsampled flow
+                gcoarse = torch.empty(B, 2, H // 2, W // 2, device=src.device, dtype=torch.float32)
+                _call('arflow_up2_bwd', _p(gfull), _p(gcoarse), B, H, W, up_align, _stream(), key=(B, H, W))
+            elif gsrc is not None:
+                _call('arflow_warp_bwd', _p(gout), _p(src), _p(flow_up), _p(gsrc), None, B, C, H, W, H, W, 2 * H * W, pad, ac, norm,
+                      _stream(), key=(B, C, H, W, True))
+        return gsrc, gcoarse, None, None, None, None
+
+
+def warp_up2(src, flow_coarse, pad='zeros', align_corners=True, norm=None, up_align=True):
+    """(flow_warp(src, up), up) with up = interpolate(flow_coarse * 2, x2, bilinear, align_corners=up_align) in one launch."""
+    return WarpUp2Function.apply(src, flow_coarse, PAD[pad], align_corners, NORM_ARFLOW if norm is None else norm, up_align)
+
+
+def warp_up2_supported(src, flow_coarse):
+    return (src.is_cuda and src.dtype == torch.float32 and flow_coarse is not None and flow_coarse.is_cuda and src.shape[2] % 2 == 0
+            and src.shape[3] % 2 == 0 and tuple(flow_coarse.shape[2:]) == (src.shape[2] // 2, src.shape[3] // 2)
+            and flow_coarse.shape[1] == 2)
+
+
 class WarpBF16Function(torch.autograd.Function):
     """Bilinear warp with the SOURCE stored as bf16 (opt-in): sampling arithmetic, output and
     both gradients fp32; the source is rounded to bf16 once and kept as such for the backward."""

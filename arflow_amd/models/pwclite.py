@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as AF
 from ..correlation import Correlation
 from ..warp_utils import flow_warp
 from .blocks import (ContextNetwork, FeatureExtractor, FlowEstimatorDense, FlowEstimatorReduce, conv,
@@ -46,6 +47,9 @@ class PWCLite(nn.Module):
         for l, (x1, x2) in enumerate(zip(x1_pyramid, x2_pyramid)):
             if l == 0:
                 x2_warp = x2
+            elif AF.warp_up2_supported(x2, flow):
+                # flow x2 upsample (models/pwclite.py:178-179) folded into the warp launch
+                x2_warp, flow = AF.warp_up2(x2, flow, up_align=True)
             else:
                 flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
                 x2_warp = flow_warp(x2, flow)
@@ -82,6 +86,8 @@ class PWCLite(nn.Module):
             neighbours = torch.cat([x0, x2], 0)
             if flow is None:
                 flow = torch.zeros(2 * B, 2, *x1.shape[2:], dtype=torch.float32, device=x1.device)
+            elif AF.warp_up2_supported(neighbours, flow):
+                neighbours, flow = AF.warp_up2(neighbours, flow, up_align=True)
             else:
                 flow = F.interpolate(flow * 2, scale_factor=2, mode='bilinear', align_corners=True)
                 neighbours = flow_warp(neighbours, flow)

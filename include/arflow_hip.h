@@ -181,6 +181,10 @@ int arflow_level_bwd(const float* gout, long gout_bstride, const unsigned* sign_
                      int flow_is_coarse, int up_align_corners, void* workspace, int B, int C, int H, int W, int max_disp,
                      float negative_slope, int pad_mode, int align_corners, int coord_norm, arflow_stream_t stream);
 int arflow_level_acc_rows(int B, int C, int H, int W, int has_flow);
+/* Adjoint of the x2 bilinear flow upsample of arflow_level_warp_fwd (flow_up = interpolate(flow * 2, scale 2),
+ * models/pwclite.py:178-179, utils/uflow_utils.py:163-180 upsample(is_flow)): gfine [B,2,H,W] -> gcoarse [B,2,H/2,W/2],
+ * every element written (no zero-fill needed). */
+int arflow_up2_bwd(const float* gfine, float* gcoarse, int B, int H, int W, int up_align_corners, arflow_stream_t stream);
 int arflow_level_moments(const float* x1, const float* x2, double* acc, int B, long n, arflow_stream_t stream);
 int arflow_level_warp_fwd(const float* x1, const float* x2, const float* flow, long flow_bstride, int flow_is_coarse,
                           int up_align_corners, float* flow_up, float* flow_up2, long flow_up2_bstride, float* x2w,

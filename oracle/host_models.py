@@ -29,13 +29,19 @@ def oracle_ops(model):
     import arflow_amd.models.pwclite_uflow as mpu
     import arflow_amd.models.uflow_model as mum
     import arflow_amd.models.blocks as mb
-    saved = [(mp, 'flow_warp', mp.flow_warp), (mpu, 'flow_warp', mpu.flow_warp),
+    import arflow_amd.functional as AF
+    saved = [(AF, 'level_supported', AF.level_supported), (AF, 'warp_up2_supported', AF.warp_up2_supported),
+             (mp, 'flow_warp', mp.flow_warp), (mpu, 'flow_warp', mpu.flow_warp),
              (mum, 'cost_volume_concat', mum.cost_volume_concat),
              (mum.uflow_utils, 'resample_flow', mum.uflow_utils.resample_flow),
              (mpu, 'normalize_features', mpu.normalize_features), (mum, 'normalize_features', mum.normalize_features),
              (mb, 'bias_act', mb.bias_act)]
     old_corr = getattr(model, 'corr', None)
     try:
+        # the fused level / upsample-fused warp launches are HIP ops too: off, so that a twin on the GPU runs the op-by-op
+        # wiring with the oracle ops below (on the CPU they are off anyway)
+        AF.level_supported = lambda *a, **k: False
+        AF.warp_up2_supported = lambda *a, **k: False
         mp.flow_warp = O.flow_warp
         mpu.flow_warp = O.flow_warp
         mum.cost_volume_concat = lambda a, b, before, after, max_displacement, negative_slope=1.0: OracleCorrelation(

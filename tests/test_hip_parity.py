@@ -651,6 +651,32 @@ def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, family, 
     assert torch.equal(mask3, valid)
 
 
+@pytest.mark.parametrize('up_align', [True, False])
+@pytest.mark.parametrize('shape,pad', [((2, 8, 12, 20), 'zeros'), ((3, 32, 24, 40), 'border'), ((2, 96, 12, 20), 'zeros'), ((1, 5, 6, 10), 'zeros')],
+                         ids=lambda v: str(v))
+def test_warp_with_fused_flow_upsample_vs_oracle(AF, oracle, shape, pad, up_align):
+    """warp_up2 (arflow_level_warp_fwd + arflow_warp_bwd + arflow_up2_bwd: the x2 flow upsample of models/pwclite.py:178-179
+    folded into the warp launch) against interpolate(flow * 2) + the oracle's flow_warp: warped map, upsampled flow and the
+    gradients w.r.t. the source and the COARSE flow (with a second consumer of the upsampled flow, like the estimator)."""
+    B, C, H, W = shape
+    gen = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=gen)
+    fc = 1.5 * torch.randn(B, 2, H // 2, W // 2, generator=gen)
+    go, gf = torch.randn(B, C, H, W, generator=gen), torch.randn(B, 2, H, W, generator=gen)
+    xr, fr = x.clone().requires_grad_(True), fc.clone().requires_grad_(True)
+    up = torch.nn.functional.interpolate(fr * 2, scale_factor=2, mode='bilinear', align_corners=up_align)
+    ref = oracle.flow_warp(xr, up, pad=pad)
+    gxr, gfr = torch.autograd.grad([ref, up], [xr, fr], [go, gf])
+    xc, fcu = cu(x).requires_grad_(True), cu(fc).requires_grad_(True)
+    out, upc = AF.warp_up2(xc, fcu, pad=pad, align_corners=True, up_align=up_align)
+    gx, gfl = torch.autograd.grad([out, upc], [xc, fcu], [cu(go), cu(gf)])
+    mx = float(x.abs().max())
+    assert_close(upc, up.detach(), 2e-6, 2e-6, 'upsampled flow')  # ATen's CPU kernel associates the 4 products differently
+    assert_close(out, ref.detach(), (2e-6 + 4 * 1.2e-7 * max(H, W)) * mx * 4, 1e-5, 'warped map')
+    assert_close(gx, gxr, 1e-5, 1e-4, 'd src')
+    assert_close(gfl, gfr, 1e-5 * (1 + float(gfr.abs().max())), 1e-4, 'd coarse flow')
+
+
 @pytest.mark.parametrize('family', ['column', 'ordered'])
 @pytest.mark.parametrize('patch', [3, 5])
 def test_fused_census_warp_small_patches_vs_oracle(AF, oracle, patch, family, monkeypatch):
