@@ -97,6 +97,9 @@ def algorithmic_bytes(name, shape):
         B, C, H, W, d, act, fk = shape
         flow = {0: 0.0, 1: 2.0 + 2.0, 2: 2.0 + 4.0 + 0.5}[fk]
         return int(4 * B * H * W * ((2 * d + 1) ** 2 + act + (7 if fk else 6) * C + flow))
+    if name == 'arflow_up2_bwd':  # fine flow gradient [B,2,H,W] in, coarse one out
+        B, H, W = shape[:3]
+        return 4 * B * 2 * (H * W + (H // 2) * (W // 2))
     if name == 'arflow_level_warp_fwd':  # x1 (moments), x2 in; x2w out; coarse flow in, upsampled flow out twice
         B, C, H, W, up = shape
         return 4 * B * H * W * (3 * C + 2) + (4 * B * H * W * 2 + 2 * B * H * W if up else 0)
