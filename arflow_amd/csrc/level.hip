@@ -20,8 +20,9 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr int SLAB_CAP = 768;  // cells per tile slab: windows up to e.g. 16 x 48 (a smooth flow gives ~10 x 36)
 struct BwdWs {
-  size_t g1, g2, gfl, acc, slab, meta, ovf, total;
+  size_t g1, g2, gfl, acc, slab, meta, ovf, qinfo, total;
   int slab_cap;
+  bool gather;  // fine level: d/d src of the warp as a gather over the inverse-flow window (warp.hip inv_gather)
 };
 inline BwdWs bwd_layout(int B, int C, int H, int W) {
   BwdWs w;
@@ -40,7 +41,21 @@ inline BwdWs bwd_layout(int B, int C, int H, int W) {
   w.slab_cap = (slab_on && tiles >= 768 && tiles / B <= 1024) ? SLAB_CAP : 0;
   w.meta = w.slab + align256(sizeof(float) * tiles * C * (size_t)w.slab_cap);
   w.ovf = w.meta + align256(16 * tiles);
-  w.total = w.ovf + align256(sizeof(int) * (size_t)B);
+  w.qinfo = w.ovf + align256(sizeof(int) * (size_t)B);
+  // OPT-IN (ARFLOW_WARP_GATHER=1).  Built, parity-green, measured in the bench step (B16 C32 96x160): the gather kernel takes
+  // 29.6 us against 63 us for the atomic scatter and the correlation backward loses its 31 MB zero-fill (85 -> 79 us), but
+  // the flows of the RANDOM-INIT network the bench runs are rough (tools/flow_roughness.py: |f(p) - f(q)| <= 2 px for only 58 %
+  // of the tap pairs, tile window boxes 7 rows taller than the tile on average), so 40 % of the pairs fall to the per-pair
+  // atomics of the flow-gradient role: 135-368 us for that launch, 365 vs 234 us for the level.  For the smooth flows of a
+  // trained network the balance is the other way round.
+  static const bool gather_on = [] {
+    const char* e = getenv("ARFLOW_WARP_GATHER");
+    return e && e[0] == '1';
+  }();
+  // (below ~768 tiles the two gradient roles share one launch and the atomics are not the bound: the gather form would add
+  // a launch)
+  w.gather = gather_on && !w.slab_cap && tiles >= 768 && H <= 4095 && W <= 4095;
+  w.total = w.qinfo + (w.gather ? align256(sizeof(int) * (size_t)B * H * W) : 0);
   return w;
 }
 }  // namespace
@@ -176,8 +191,9 @@ extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsi
   // (the upsample's adjoint through float atomics inside the warp launch was tried for the coarse levels: the channel-split
   // workgroups of a tile all add into the same few coarse cells -- 24x40 backward 48 -> 77 us; the gather kernel stays)
   const bool up_atomic = false;
+  const bool gather = has_flow && ws.gather;  // gx2 is then written, not accumulated: no zero-fill
   int rc = af_level_corr_bwd_launch(gout, gout_bstride, sign_bits, x1n, x1n_bstride, second, stats, g1, g2, B, C, H, W,
-                                    negative_slope, st, has_flow ? gx2 : nullptr,
+                                    negative_slope, st, (has_flow && !gather) ? gx2 : nullptr,
                                     has_flow ? (flow_is_coarse ? gfl : gflow) : nullptr, up_atomic ? gflow : nullptr,
                                     slab ? ovf : nullptr);
   if (rc != ARFLOW_OK) return rc;
@@ -192,7 +208,7 @@ extern "C" int arflow_level_bwd(const float* gout, long gout_bstride, const unsi
   rc = af_level_warp_bwd_launch(g2, x2, x2w, flow_full, flow_bstride, gx2, flow_is_coarse ? gfl : gflow, B, C, H, W, pad_mode,
                                 align_corners, coord_norm, acc, nrows, stats, norm_mode, g1, gx1n_direct, gx1n_direct_bstride,
                                 x1, gx1, gflow_a, gflow_a_bstride, gflow_b, up_atomic ? gflow : nullptr, up_align_corners, slab,
-                                base + ws.meta, ovf, ws.slab_cap, st);
+                                base + ws.meta, ovf, ws.slab_cap, gather ? (int*)(base + ws.qinfo) : nullptr, st);
   if (rc != ARFLOW_OK || !flow_is_coarse || up_atomic) return rc;
   return af_up2_bwd_launch(gfl, gflow, B * 2, H, W, up_align_corners, st);
 }

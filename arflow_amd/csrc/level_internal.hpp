@@ -21,7 +21,7 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
                              int norm_mode, const double* rows, int nrows, const float* stats, int featnorm_mode,
                              const float* g1n, const float* gdir, long gdir_bs, const float* x1, float* gx1,
                              const float* add1, long add1_bs, const float* add2, float* gcoarse, int up_align,
-                             float* slab, void* slab_meta, int* slab_ovf, int slab_cap, hipStream_t st);
+                             float* slab, void* slab_meta, int* slab_ovf, int slab_cap, int* qinfo, hipStream_t st);
 int af_featnorm_bwd_sums_launch(const float* g1, const float* g1b, long g1b_bs, const float* g2, const float* x1,
                                 const float* x2, const float* stats, double* acc, int* nrows, int B, long n, hipStream_t st);
 int af_up2_bwd_launch(const float* gfine, float* gcoarse, int planes, int H, int W, int up_align, hipStream_t st);

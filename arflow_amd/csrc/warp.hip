@@ -414,6 +414,13 @@ __device__ __forceinline__ TileBox tile_bbox(const Taps& t, int (*red)[4], int* 
 // d coord / d flow.  Same tile / LDS source-window structure as the forward kernel; this is the whole
 // backward of the loss-side image warps (their source is detached, losses/uflow_loss.py:31,34).
 // ------------------------------------------------------------------------------------------------
+// (inverse-window gather of d/d src, inv_gather below: does that kernel take the pair (target p, source q)?  qinfo = window
+// centre of q (13 + 13 bits, biased by 4096) + bit 30 = "q is left to the atomics")
+__device__ __forceinline__ bool af_gather_takes(int qinfo, int px, int py, int m) {
+  const int cx = (qinfo & 0x1fff) - 4096, cy = ((qinfo >> 13) & 0x1fff) - 4096;
+  return !(qinfo & (1 << 30)) && abs(px - cx) <= m && abs(py - cy) <= m;
+}
+
 namespace flow_grad {
 using fwd_win::HMAX;
 // NB (level backward): `gop` holds the gradient of the NORMALISED warped map; the normalisation's backward
@@ -446,7 +453,10 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
                                     int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
                                     float& gix, float& giy, const NormBwd* nb = nullptr,
                                     const float* __restrict__ g1p = nullptr, const float* __restrict__ gdp = nullptr,
-                                    const float* __restrict__ x1p = nullptr, float* __restrict__ d1p = nullptr) {
+                                    const float* __restrict__ x1p = nullptr, float* __restrict__ d1p = nullptr,
+                                    float* __restrict__ fixp = nullptr, unsigned fixmask = 0u) {
+  // fixp / fixmask (level backward with the gather form of d/d src): taps of this pixel that the gather kernel did NOT
+  // take (bit k of fixmask) are added to d/d src here, with float atomics -- fixp = that tensor at this sample
   constexpr int WP = 4 * WQ;
   using fwd_win::WindowPlan;
   const WindowPlan<WQ> pl = fwd_win::window_plan<WQ>(Ws, ax0, by0, bh);
@@ -498,6 +508,11 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
       }
       gix = fmaf(gc, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
       giy = fmaf(gc, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
+      if (NB && fixmask && c0 + c < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((fixmask >> k) & 1u) atomicAdd(fixp + (long)(c0 + c) * ss + p.o[k], gc * p.w[k]);
+      }
     }
     __syncthreads();
   }
@@ -590,6 +605,8 @@ struct LevelBwdArgs {
   float* d1;
   float* gcoarse;  // non-null: the flow gradient goes straight through the adjoint of the x2 upsample into this PRE-ZEROED
   int up_align;    // [B,2,H/2,W/2] tensor with float atomics (coarse levels: one launch less than up2_bwd_kernel)
+  const int* qinfo = nullptr;  // gather form of d/d src (inv_gather): per source pixel, written by gather_kernel
+  float* gfix = nullptr;       // d/d src [B,C,H,W]: the pairs the gather kernel did not take are added here
 };
 __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict__ g2n, const float* __restrict__ src,
                                                          const float* __restrict__ flow, float* __restrict__ gflow,
@@ -627,6 +644,16 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
   const float* x1p = la.x1 + po;
   float* d1p = la.d1 + po;
   float gix = 0.f, giy = 0.f;
+  // gather form of d/d src: which of this pixel's taps the gather kernel did not take (they are added here)
+  unsigned fixmask = 0u;
+  float* fixp = nullptr;
+  if (la.qinfo && inside) {
+    const int* qi = la.qinfo + (long)b * ss;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (p.ok[k] && !af_gather_takes(qi[p.o[k]], x, y, 3)) fixmask |= 1u << k;
+    fixp = la.gfix + (long)b * C * ss;
+  }
   if (!empty && (Ws & 3) == 0 && bh <= HMAX && aw <= 72) {
     const int xa = min(max(t.x0, 0), Ws - 1) - ax0, xb = min(max(t.x0 + 1, 0), Ws - 1) - ax0;
     const int ya = min(max(t.y0, 0), Hs - 1) - bb.y0, yb = min(max(t.y0 + 1, 0), Hs - 1) - bb.y0;
@@ -634,10 +661,12 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
     const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
     if (aw <= 48)
       flow_grad::run<12, CCH, float, true>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa,
-                                           cya * 48 + cxb, cyb * 48 + cxa, cyb * 48 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p);
+                                           cya * 48 + cxb, cyb * 48 + cxa, cyb * 48 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p,
+                                           fixp, fixmask);
     else
       flow_grad::run<18, CCH, float, true>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa,
-                                           cya * 72 + cxb, cyb * 72 + cxa, cyb * 72 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p);
+                                           cya * 72 + cxb, cyb * 72 + cxa, cyb * 72 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p,
+                                           fixp, fixmask);
   } else if (inside) {
     for (int c = blockIdx.y; c < C; c += gridDim.y) {  // no tap inside the source, or a window too large: direct gathers
       const float gsum = g1p[(long)c * os] + (gdp ? gdp[(long)c * os] : 0.f);
@@ -651,6 +680,11 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
       const float g = flow_grad::norm_bwd_apply(nb, gop[(long)c * os], xw, nb.c2);
       gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
       giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
+      if (fixmask) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((fixmask >> k) & 1u) atomicAdd(fixp + (long)c * ss + p.o[k], g * p.w[k]);
+      }
     }
   }
   if (inside) {
@@ -1099,6 +1133,184 @@ __global__ __launch_bounds__(256) void level_warp_bwd_both_kernel(const float* _
     level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la, bx);
 }
 
+// ------------------------------------------------------------------------------------------------
+// d loss / d src of the warp as a GATHER over the inverse-flow window (level backward, fine level; round 3).
+//
+// The scatter form above ends in ~10 M float atomics (180-260 G/s on MI355X whatever their shape, tools/ubench/
+// atomic_shape.hip): >= 50 us at B16 C32 96x160.  For the flows a pyramid level sees (the x2 upsample of the coarser
+// estimate: smooth except at motion boundaries) the targets p whose taps hit a source pixel q lie within a few pixels of
+// q - flow(q).  So every source pixel q scans the (2M+1)^2 targets p around c(q) = q - round(flow(q)) against the taps of
+// those targets (computed once per workgroup, staged in LDS), keeps the (p, weight) pairs whose tap IS q, and sums
+// w * g[c, p] per channel out of an LDS-staged tile of gradients: plain stores, every element of gsrc written (no
+// zero-fill), a fixed summation order.
+// Exactness for ANY flow: a pair (p, q) outside q's window -- or a q whose list overflows, or a tile whose window box does
+// not fit LDS -- is added by the flow-gradient role instead, which visits every p with its four taps anyway: it reads
+// qinfo[q] (window centre + flag, written here) and issues the float atomic iff THIS kernel did not take the pair (same
+// predicate on both sides: the pairs are partitioned, none is lost or counted twice).  On the flows of a training step
+// those atomics are rare.
+// ------------------------------------------------------------------------------------------------
+namespace inv_gather {
+constexpr int TX = 32, TY = 8, NT = 256, M = 3, RW = 48, RH = 16, RMAX = RW * RH, K = 8, CCH = 4;
+constexpr int QFLAG = 1 << 30;
+__device__ __forceinline__ int pack_q(int cx, int cy, bool flag) {  // cx, cy in [-4096, 4095] after the clamp below
+  return ((cx + 4096) & 0x1fff) | (((cy + 4096) & 0x1fff) << 13) | (flag ? QFLAG : 0);
+}
+__device__ __forceinline__ void unpack_q(int v, int& cx, int& cy, bool& flag) {
+  cx = (v & 0x1fff) - 4096, cy = ((v >> 13) & 0x1fff) - 4096, flag = (v & QFLAG) != 0;
+}
+// does the gather kernel take the pair (target p, source q)?  (the ONE predicate both kernels use)
+__device__ __forceinline__ bool taken(int qinfo, int px, int py) {
+  int cx, cy;
+  bool flag;
+  unpack_q(qinfo, cx, cy, flag);
+  return !flag && abs(px - cx) <= M && abs(py - cy) <= M;
+}
+
+__global__ __launch_bounds__(NT) void gather_kernel(const float* __restrict__ g2n, const float* __restrict__ x2w,
+                                                    const float* __restrict__ flow, float* __restrict__ gsrc,
+                                                    int* __restrict__ qinfo, int nimg, int C, int H, int W, long fbs, int pad,
+                                                    int align, int norm, const double* __restrict__ rows, int nrows,
+                                                    const float* __restrict__ stats, int mode) {
+  __shared__ int tinfo[RMAX];                                   // x0 + 1 | (y0 + 1) << 13 | valid bits << 26
+  __shared__ __attribute__((aligned(16))) float4 twts[RMAX];    // wx0, wx1, wy0, wy1
+  __shared__ float gbuf[CCH][RMAX];
+  __shared__ int red[4][4];
+  __shared__ int box[4];
+  int btx, bty, b;
+  if (!af_tile_of_block((W + TX - 1) / TX, (H + TY - 1) / TY, nimg, btx, bty, b)) return;
+  const int x = btx * TX + (int)(threadIdx.x & 31), y = bty * TY + (int)(threadIdx.x >> 5);
+  const bool inside = x < W && y < H;
+  const long os = (long)H * W;
+  const float* fb = flow + (long)b * fbs;
+  // window centre of this source pixel
+  int cx = 0, cy = 0;
+  bool bad = !inside;
+  if (inside) {
+    const float u = fb[(long)y * W + x], v = fb[os + (long)y * W + x];
+    if (fabsf(u) < 4000.f && fabsf(v) < 4000.f)
+      cx = x - (int)rintf(u), cy = y - (int)rintf(v);
+    else
+      bad = true;  // NaN / absurd flow: leave the pixel to the atomics
+  }
+  // box of the windows (clamped to the image) over the tile
+  int lo_x = bad ? 0x7fffffff : max(cx - M, 0), hi_x = bad ? -0x7fffffff : min(cx + M, W - 1);
+  int lo_y = bad ? 0x7fffffff : max(cy - M, 0), hi_y = bad ? -0x7fffffff : min(cy + M, H - 1);
+  if (!bad && (lo_x > hi_x || lo_y > hi_y)) lo_x = 0x7fffffff, hi_x = -0x7fffffff, lo_y = 0x7fffffff, hi_y = -0x7fffffff;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_x = min(lo_x, __shfl_xor(lo_x, off, 64)), lo_y = min(lo_y, __shfl_xor(lo_y, off, 64));
+    hi_x = max(hi_x, __shfl_xor(hi_x, off, 64)), hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[0][wave] = lo_x, red[1][wave] = lo_y, red[2][wave] = hi_x, red[3][wave] = hi_y;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = red[0][0], bb = red[1][0], c = red[2][0], d = red[3][0];
+    for (int w = 1; w < 4; ++w) a = min(a, red[0][w]), bb = min(bb, red[1][w]), c = max(c, red[2][w]), d = max(d, red[3][w]);
+    box[0] = a, box[1] = bb, box[2] = c, box[3] = d;
+  }
+  __syncthreads();
+  const int rx0 = box[0], ry0 = box[1];
+  const int rw = box[2] - rx0 + 1, rh = box[3] - ry0 + 1;
+  const bool none = box[2] < rx0;                          // no pixel of the tile has a window inside the image
+  const bool oversize = !none && (rw > RW || rh > RH);     // workgroup-uniform
+  const int nr = (none || oversize) ? 0 : rw * rh;
+  // taps of the targets in the box, once per workgroup
+  for (int i = threadIdx.x; i < nr; i += NT) {
+    const int r = i / rw, c = i - r * rw;
+    const int px = rx0 + c, py = ry0 + r;
+    const Taps t = make_taps((float)px, (float)py, fb[(long)py * W + px], fb[os + (long)py * W + px], H, W, H, W, pad,
+                             align != 0, norm);
+    const int vb = (t.vx0 ? 1 : 0) | (t.vx1 ? 2 : 0) | (t.vy0 ? 4 : 0) | (t.vy1 ? 8 : 0);
+    tinfo[i] = ((t.x0 + 1) & 0x1fff) | (((t.y0 + 1) & 0x1fff) << 13) | (vb << 26);
+    twts[i] = make_float4(t.wx0, t.wx1, t.wy0, t.wy1);
+  }
+  __syncthreads();
+  // this pixel's contributors
+  int lidx[K];
+  float lw[K];
+  int n = 0;
+  bool flag = bad || oversize;
+#pragma unroll
+  for (int k = 0; k < K; ++k) lidx[k] = 0, lw[k] = 0.f;
+  if (!flag && !none) {
+    for (int dy = -M; dy <= M; ++dy) {
+      const int py = cy + dy;
+      if (py < 0 || py >= H) continue;
+      for (int dx = -M; dx <= M; ++dx) {
+        const int px = cx + dx;
+        if (px < 0 || px >= W) continue;
+        const int i = (py - ry0) * rw + (px - rx0);
+        const int ti = tinfo[i];
+        const int ddx = x - ((ti & 0x1fff) - 1), ddy = y - (((ti >> 13) & 0x1fff) - 1);
+        if ((unsigned)ddx > 1u || (unsigned)ddy > 1u) continue;
+        const int vb = ti >> 26;
+        if (!((vb >> ddx) & 1) || !((vb >> (2 + ddy)) & 1)) continue;
+        const float4 w4 = twts[i];
+        const float w = (ddx ? w4.y : w4.x) * (ddy ? w4.w : w4.z);
+        if (n < K) {
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+            if (k == n) lidx[k] = i, lw[k] = w;
+        }
+        ++n;
+      }
+    }
+    if (n > K) flag = true, n = 0;  // (convergent flow: more contributors than the list holds)
+  }
+  if (flag) n = 0;
+  if (inside && blockIdx.y == 0) qinfo[(long)b * os + (long)y * W + x] = pack_q(max(min(cx, 4095), -4096), max(min(cy, 4095), -4096), flag);
+  // (a clamped centre can only belong to a pixel whose window lies outside the image: nothing is taken for it either way)
+  const flow_grad::NormBwd nb = flow_grad::norm_bwd_coeffs(rows + 4L * nrows * b, nrows, stats + 4 * b, (long)C * os, mode);
+  const float* gp = g2n + (long)b * C * os;
+  const float* xp = x2w + (long)b * C * os;
+  float* op = gsrc + (long)b * C * os + (long)y * W + x;
+  constexpr int ITER = RMAX / NT;  // 3
+  const int step = gridDim.y * CCH;
+  int c0 = blockIdx.y * CCH;
+  float gv[CCH][ITER], xv[CCH][ITER];
+  auto fetch = [&](int cc) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = threadIdx.x + it * NT;
+      const int r = i / max(rw, 1), c = i - r * max(rw, 1);
+      const long o = i < nr ? (long)(ry0 + r) * W + rx0 + c : 0;
+#pragma unroll
+      for (int k = 0; k < CCH; ++k) {
+        const long co = (long)min(cc + k, C - 1) * os + o;
+        gv[k][it] = gp[co], xv[k][it] = xp[co];
+      }
+    }
+  };
+  if (c0 < C) fetch(c0);
+  for (; c0 < C; c0 += step) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int i = threadIdx.x + it * NT;
+      if (i < nr) {
+#pragma unroll
+        for (int k = 0; k < CCH; ++k) gbuf[k][i] = flow_grad::norm_bwd_apply(nb, gv[k][it], xv[k][it], nb.c2);
+      }
+    }
+    if (c0 + step < C) fetch(c0 + step);
+    __syncthreads();
+    if (inside) {
+#pragma unroll
+      for (int k = 0; k < CCH; ++k) {
+        if (c0 + k >= C) break;
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < K; ++e)
+          if (e < n) sum = fmaf(lw[e], gbuf[k][lidx[e]], sum);
+        op[(long)(c0 + k) * os] = sum;
+      }
+    }
+    __syncthreads();
+  }
+}
+}  // namespace inv_gather
+
+// ------------------------------------------------------------------------------------------------
 // Forward splat of the 4 bilinear weights of every pixel's target position (compute_range_map /
 // get_corresponding_map).  One workgroup = an 8 x 32 tile of source pixels; their targets fall into a
 // small window that is accumulated in LDS with INTEGER atomics on 2^-22 fixed-point weights
@@ -1392,8 +1604,9 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
                              int norm_mode, const double* rows, int nrows, const float* stats, int featnorm_mode,
                              const float* g1n, const float* gdir, long gdir_bs, const float* x1, float* gx1,
                              const float* add1, long add1_bs, const float* add2, float* gcoarse, int up_align,
-                             float* slab, void* slab_meta, int* slab_ovf, int slab_cap, hipStream_t st) {
+                             float* slab, void* slab_meta, int* slab_ovf, int slab_cap, int* qinfo, hipStream_t st) {
   // gx2, gflow (and gcoarse, slab_ovf) arrive ZERO-FILLED (by the correlation backward launch in front of this one)
+  // -- except gx2 in the gather form (qinfo != null): gather_kernel writes every element of it
   const long per = (long)af_cdiv(W, 32) * af_cdiv(H, 8);
   const long tiles = per * B;
   const unsigned nsplit = channel_split(tiles, C);
@@ -1403,6 +1616,15 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
   // ARFLOW_WARP_SLAB=1): built, parity-green, measured SLOWER at B16 C32 96x160 -- stores 39 us + gather 33 us vs 64 us for
   // the atomic flush; it is bit-reproducible across workgroup scheduling, the atomics are not
   const bool want_slab = slab != nullptr && per <= lds_scatter::MAXT;
+  if (qinfo) {  // fine level: d/d src as a gather over the inverse-flow window, then the flow-gradient role + the pairs it left
+    hipLaunchKernelGGL(inv_gather::gather_kernel, grid, dim3(256), 0, st, g2n, x2w, flow, gx2, qinfo, B, C, H, W, flow_bstride,
+                       pad_mode, align_corners, norm_mode, rows, nrows, stats, featnorm_mode);
+    AF_LAUNCH_CHECK();
+    la.qinfo = qinfo, la.gfix = gx2;
+    hipLaunchKernelGGL(level_warp_bwd_flow_kernel, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
+                       pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
+    return af_launch_status();
+  }
   if (tiles * nsplit <= 2048 && !want_slab) {  // both roles in one launch
     hipLaunchKernelGGL(level_warp_bwd_both_kernel, dim3(2 * grid.x, grid.y), dim3(256), 0, st, g2n, x2, x2w, flow, gx2, gflow,
                        B, C, H, W, flow_bstride, pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);

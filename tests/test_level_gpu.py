@@ -194,17 +194,18 @@ def test_level_uflow_layout(AF, O, shape):
         assert_close(g, r, 2e-5 * float(r.abs().max()) + 1e-6, 1e-4, n)
 
 
-@pytest.mark.parametrize('env', [{'ARFLOW_WARP_SLAB': '1'}, {'ARFLOW_LEVEL_SMALL': '0'}],
-                         ids=['two-pass-slab', 'no-per-sample-kernel'])
+@pytest.mark.parametrize('env', [{'ARFLOW_WARP_SLAB': '1'}, {'ARFLOW_LEVEL_SMALL': '0'}, {'ARFLOW_WARP_GATHER': '1'}],
+                         ids=['two-pass-slab', 'no-per-sample-kernel', 'inverse-window-gather'])
 def test_opt_in_kernel_variants_in_a_fresh_process(env):
     """The library reads ARFLOW_WARP_SLAB / ARFLOW_LEVEL_SMALL once per process (they size workspaces), so the variants they
-    select -- the atomics-free two-pass form of the warp's source gradient, the tiled kernels at the coarsest
-    level -- are exercised by re-running the oracle comparison of the shapes they affect in a child process."""
+    select -- the atomics-free two-pass form of the warp's source gradient, its gather form over the inverse-flow window
+    (DESIGN.md 4.1), the tiled kernels at the coarsest level -- are exercised by re-running the oracle comparison of the shapes they affect in a child process."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sel = {'ARFLOW_WARP_SLAB': '16x32x96x160 and joint', 'ARFLOW_LEVEL_SMALL': '16x32x12x20'}[next(iter(env))]
+    sel = {'ARFLOW_WARP_SLAB': '16x32x96x160 and joint', 'ARFLOW_LEVEL_SMALL': '16x32x12x20',
+           'ARFLOW_WARP_GATHER': '(16x32x96x160 or 8x32x112x256)'}[next(iter(env))]
     cmd = [sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_level_gpu.py'), '-q', '-x', '-m', 'gpu', '-k',
            'test_level_forward_backward_vs_oracle and ' + sel]
     r = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
