@@ -447,7 +447,7 @@ __device__ __forceinline__ float norm_bwd_apply(const NormBwd& nb, float g, floa
   return fmaf(nb.rf, g, -nb.cg) - nb.cq * (x - c);
 }
 
-template <int WQ, int CCH, typename TS, bool NB = false>
+template <int WQ, int CCH, typename TS, bool NB = false, bool FIX = false>
 __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restrict__ sp,
                                     const float* __restrict__ gop, const TapPlan& p, const Taps& t, bool inside, int C,
                                     int ss, int os, int Ws, int ax0, int by0, int bh, int l0, int l1, int l2, int l3,
@@ -508,7 +508,7 @@ __device__ __forceinline__ void run(float* __restrict__ win, const TS* __restric
       }
       gix = fmaf(gc, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
       giy = fmaf(gc, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
-      if (NB && fixmask && c0 + c < C) {
+      if (NB && FIX && fixmask && c0 + c < C) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if ((fixmask >> k) & 1u) atomicAdd(fixp + (long)(c0 + c) * ss + p.o[k], gc * p.w[k]);
@@ -608,6 +608,7 @@ struct LevelBwdArgs {
   const int* qinfo = nullptr;  // gather form of d/d src (inv_gather): per source pixel, written by gather_kernel
   float* gfix = nullptr;       // d/d src [B,C,H,W]: the pairs the gather kernel did not take are added here
 };
+template <bool FIX = false>  // FIX: the gather form of d/d src is in front (la.qinfo): add the pairs it left
 __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict__ g2n, const float* __restrict__ src,
                                                          const float* __restrict__ flow, float* __restrict__ gflow,
                                                          int nimg, int C, int H, int W, long fbs, int pad, int align,
@@ -647,7 +648,7 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
   // gather form of d/d src: which of this pixel's taps the gather kernel did not take (they are added here)
   unsigned fixmask = 0u;
   float* fixp = nullptr;
-  if (la.qinfo && inside) {
+  if (FIX && la.qinfo && inside) {
     const int* qi = la.qinfo + (long)b * ss;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -660,13 +661,13 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
     const int cxa = min(max(xa, 0), 71), cxb = min(max(xb, 0), 71);
     const int cya = min(max(ya, 0), HMAX - 1), cyb = min(max(yb, 0), HMAX - 1);
     if (aw <= 48)
-      flow_grad::run<12, CCH, float, true>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa,
-                                           cya * 48 + cxb, cyb * 48 + cxa, cyb * 48 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p,
-                                           fixp, fixmask);
+      flow_grad::run<12, CCH, float, true, FIX>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 48 + cxa,
+                                                cya * 48 + cxb, cyb * 48 + cxa, cyb * 48 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p,
+                                                fixp, fixmask);
     else
-      flow_grad::run<18, CCH, float, true>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa,
-                                           cya * 72 + cxb, cyb * 72 + cxa, cyb * 72 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p,
-                                           fixp, fixmask);
+      flow_grad::run<18, CCH, float, true, FIX>(win, sp, gop, p, t, inside, C, ss, os, Ws, ax0, bb.y0, bh, cya * 72 + cxa,
+                                                cya * 72 + cxb, cyb * 72 + cxa, cyb * 72 + cxb, gix, giy, &nb, g1p, gdp, x1p, d1p,
+                                                fixp, fixmask);
   } else if (inside) {
     for (int c = blockIdx.y; c < C; c += gridDim.y) {  // no tap inside the source, or a window too large: direct gathers
       const float gsum = g1p[(long)c * os] + (gdp ? gdp[(long)c * os] : 0.f);
@@ -680,7 +681,7 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
       const float g = flow_grad::norm_bwd_apply(nb, gop[(long)c * os], xw, nb.c2);
       gix = fmaf(g, (ne - nw) * t.wy0 + (se - sw) * t.wy1, gix);
       giy = fmaf(g, (sw - nw) * t.wx0 + (se - ne) * t.wx1, giy);
-      if (fixmask) {
+      if (FIX && fixmask) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if ((fixmask >> k) & 1u) atomicAdd(fixp + (long)c * ss + p.o[k], g * p.w[k]);
@@ -718,12 +719,13 @@ __device__ __forceinline__ void level_warp_bwd_flow_body(const float* __restrict
   }
 }
 
+template <bool FIX = false>
 __global__ __launch_bounds__(256) void level_warp_bwd_flow_kernel(const float* __restrict__ g2n, const float* __restrict__ src,
                                                                   const float* __restrict__ flow, float* __restrict__ gflow,
                                                                   int nimg, int C, int H, int W, long fbs, int pad, int align,
                                                                   int norm, const float* __restrict__ add1, long add1_bs,
                                                                   const float* __restrict__ add2, LevelBwdArgs la) {
-  level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la, blockIdx.x);
+  level_warp_bwd_flow_body<FIX>(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la, blockIdx.x);
 }
 
 // Adjoint of the x2 bilinear flow upsample of the level forward (up2_source), times the factor 2 of
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(256) void level_warp_bwd_both_kernel(const float* _
     lds_scatter::warp_bwd_src_body<true>(g2n, flow, gsrc, nimg, C, H, W, H, W, fbs, pad, align, norm, x2w, la.rows, la.nrows,
                                          la.stats, la.mode, bx);
   else
-    level_warp_bwd_flow_body(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la, bx);
+    level_warp_bwd_flow_body<false>(g2n, src, flow, gflow, nimg, C, H, W, fbs, pad, align, norm, add1, add1_bs, add2, la, bx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1621,7 +1623,7 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
                        pad_mode, align_corners, norm_mode, rows, nrows, stats, featnorm_mode);
     AF_LAUNCH_CHECK();
     la.qinfo = qinfo, la.gfix = gx2;
-    hipLaunchKernelGGL(level_warp_bwd_flow_kernel, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
+    hipLaunchKernelGGL(level_warp_bwd_flow_kernel<true>, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
                        pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
     return af_launch_status();
   }
@@ -1641,7 +1643,7 @@ int af_level_warp_bwd_launch(const float* g2n, const float* x2, const float* x2w
                        flow_bstride, pad_mode, align_corners, norm_mode, x2w, rows, nrows, stats, featnorm_mode);
   }
   AF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(level_warp_bwd_flow_kernel, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
+  hipLaunchKernelGGL(level_warp_bwd_flow_kernel<false>, grid, dim3(256), 0, st, g2n, x2, flow, gflow, B, C, H, W, flow_bstride,
                      pad_mode, align_corners, norm_mode, add1, add1_bs, add2, la);
   if (use_slab) {
     AF_LAUNCH_CHECK();
