@@ -33,6 +33,8 @@ PROTOTYPES = {
     'arflow_warp_bwd_bf16': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_warp_nearest_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_warp_nearest_bwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_warp_bicubic_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
+    'arflow_warp_bicubic_bwd': [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_i, c_i, c_fp],
     'arflow_ssim_fwd': [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     'arflow_ssim_bwd': [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp],
     'arflow_corr_general_out_size': [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp],

@@ -1,7 +1,7 @@
 // The REST of the reference's parameter space for the hot-path functions -- values no shipped config uses but the
 // functions accept -- as plain one-thread-per-element gfx950 kernels (correct first; nothing here is on a measured
 // path, the tuned kernels of the other files serve every configuration the reference ships):
-//   * flow_warp(mode='nearest')                                  utils/warp_utils.py:83-90 -> grid_sample nearest
+//   * flow_warp(mode='nearest' | 'bicubic')                      utils/warp_utils.py:83-90 -> grid_sample nearest / bicubic
 //   * TernaryLoss(max_distance > 3) / census_loss(patch_size > 7) losses/loss_blocks.py:12-62, utils/uflow_utils.py:241-293
 //   * SSIM(md != 1)                                              losses/loss_blocks.py:65-84
 //   * Correlation(kernel_size, stride1, stride2, pad_size != d)  models/correlation_package/correlation_cuda_kernel.cu:41-114
@@ -54,6 +54,119 @@ __global__ __launch_bounds__(256) void warp_nearest_bwd_kernel(const float* __re
   float* gp = gsrc + (long)b * C * ss + (long)yi * Ws + xi;
   const float* gop = gout + (long)b * C * os + (long)y * W + x;
   for (int c = 0; c < C; ++c) atomicAdd(gp + c * ss, gop[c * os]);
+}
+
+// ------------------------------------------------------------------------------------------------ bicubic warp
+// torch grid_sample(mode='bicubic') (ATen/native/GridSampler.h get_cubic_upsample_coefficients / get_value_bounded,
+// ATen/native/cuda/GridSampler.cu bicubic branch): A = -0.75; the 4 x 4 taps around floor(coordinate) are read at
+// BOUNDED positions (border padding clips each tap's position, zeros padding reads 0 outside); rows are interpolated
+// first, then the column; the coordinate gradient uses the derivative of the coefficients and ignores the tap clipping.
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+  const float A = -0.75f;
+  const float x1 = t, x2 = 1.0f - t;
+  c[0] = ((A * (x1 + 1.0f) - 5.0f * A) * (x1 + 1.0f) + 8.0f * A) * (x1 + 1.0f) - 4.0f * A;
+  c[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+  c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  c[3] = ((A * (x2 + 1.0f) - 5.0f * A) * (x2 + 1.0f) + 8.0f * A) * (x2 + 1.0f) - 4.0f * A;
+}
+__device__ __forceinline__ void cubic_coeffs_grad(float t, float (&g)[4]) {
+  const float A = -0.75f;
+  float x = -1.0f - t;
+  g[0] = (-3.0f * A * x - 10.0f * A) * x - 8.0f * A;
+  x = -t;
+  g[1] = (-3.0f * (A + 2.0f) * x - 2.0f * (A + 3.0f)) * x;
+  x = 1.0f - t;
+  g[2] = (3.0f * (A + 2.0f) * x - 2.0f * (A + 3.0f)) * x;
+  x = 2.0f - t;
+  g[3] = (3.0f * A * x - 10.0f * A) * x + 8.0f * A;
+}
+struct BicubicTaps {
+  int off[4][4];  // element offset of tap (row j, column i) inside a source plane, or -1 when it reads zero
+  float cx[4], cy[4], tx, ty, dx, dy;
+};
+__device__ __forceinline__ BicubicTaps bicubic_taps(float px, float py, float u, float v, int H, int W, int Hs, int Ws, int pad,
+                                                    bool align, int norm) {
+  BicubicTaps t;
+  const float ix = af_sample_coord(px, u, W, Ws, norm, align, &t.dx);
+  const float iy = af_sample_coord(py, v, H, Hs, norm, align, &t.dy);
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.tx = ix - fx, t.ty = iy - fy;
+  cubic_coeffs(t.tx, t.cx);
+  cubic_coeffs(t.ty, t.cy);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = fx - 1.0f + (float)i, y = fy - 1.0f + (float)j;  // get_value_bounded: compute_coordinates, then the cast
+      if (pad == ARFLOW_PAD_BORDER) {
+        x = fminf(fmaxf(x, 0.f), (float)(Ws - 1));
+        y = fminf(fmaxf(y, 0.f), (float)(Hs - 1));
+      }
+      const bool ok = x >= 0.f && x <= (float)(Ws - 1) && y >= 0.f && y <= (float)(Hs - 1);  // NaN -> false
+      t.off[j][i] = ok ? (int)y * Ws + (int)x : -1;
+    }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void warp_bicubic_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                               float* __restrict__ out, int C, int Hs, int Ws, int H, int W,
+                                                               long fbs, int pad, int align, int norm) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const float* fb = flow + (long)b * fbs + (long)y * W + x;
+  const BicubicTaps t = bicubic_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
+  const long ss = (long)Hs * Ws, os = (long)H * W;
+  const float* sp = src + (long)b * C * ss;
+  float* op = out + (long)b * C * os + (long)y * W + x;
+  for (int c = 0; c < C; ++c) {
+    float rows[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = t.off[j][i] >= 0 ? sp[c * ss + t.off[j][i]] : 0.f;
+      rows[j] = ((v[0] * t.cx[0] + v[1] * t.cx[1]) + v[2] * t.cx[2]) + v[3] * t.cx[3];  // cubic_interp1d
+    }
+    op[c * os] = ((rows[0] * t.cy[0] + rows[1] * t.cy[1]) + rows[2] * t.cy[2]) + rows[3] * t.cy[3];
+  }
+}
+
+// gsrc (nullable) arrives zero-filled; gflow (nullable) [B,2,H,W] is written
+__global__ __launch_bounds__(256) void warp_bicubic_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ src,
+                                                               const float* __restrict__ flow, float* __restrict__ gsrc,
+                                                               float* __restrict__ gflow, int C, int Hs, int Ws, int H, int W,
+                                                               long fbs, int pad, int align, int norm) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const float* fb = flow + (long)b * fbs + (long)y * W + x;
+  const BicubicTaps t = bicubic_taps((float)x, (float)y, fb[0], fb[(long)H * W], H, W, Hs, Ws, pad, align != 0, norm);
+  float gxc[4], gyc[4];
+  cubic_coeffs_grad(t.tx, gxc);
+  cubic_coeffs_grad(t.ty, gyc);
+  const long ss = (long)Hs * Ws, os = (long)H * W;
+  const float* sp = src + (long)b * C * ss;
+  const float* gop = gout + (long)b * C * os + (long)y * W + x;
+  float gix = 0.f, giy = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = gop[c * os];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (t.off[j][i] < 0) continue;
+        if (gsrc) atomicAdd(gsrc + (long)b * C * ss + c * ss + t.off[j][i], g * t.cx[i] * t.cy[j]);
+        if (gflow) {
+          const float v = sp[c * ss + t.off[j][i]];
+          gix -= v * gxc[i] * t.cy[j] * g;
+          giy -= v * gyc[j] * t.cx[i] * g;
+        }
+      }
+  }
+  if (gflow) {
+    float* gf = gflow + (long)b * 2 * os + (long)y * W + x;
+    gf[0] = t.dx * gix;
+    gf[os] = t.dy * giy;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ census, any radius
@@ -303,6 +416,44 @@ extern "C" int arflow_warp_nearest_bwd(const float* gout, const float* flow, flo
   if (e != hipSuccess) return af_hip_status(e);
   hipLaunchKernelGGL(warp_nearest_bwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, st, gout, flow, gsrc, C, Hs, Ws, H,
                      W, flow_bstride, pad_mode, align_corners, norm_mode);
+  return af_launch_status();
+}
+
+extern "C" int arflow_warp_bicubic_fwd(const float* src, const float* flow, float* out, int B, int C, int Hs, int Ws, int H,
+                                       int W, long flow_bstride, int pad_mode, int align_corners, int norm_mode,
+                                       arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(src);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE_PTR(out);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+  hipLaunchKernelGGL(warp_bicubic_fwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, src, flow, out,
+                     C, Hs, Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
+  return af_launch_status();
+}
+
+extern "C" int arflow_warp_bicubic_bwd(const float* gout, const float* src, const float* flow, float* gsrc, float* gflow, int B,
+                                       int C, int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode, int align_corners,
+                                       int norm_mode, arflow_stream_t stream) {
+  af_clear_stale_error();
+  AF_REQUIRE_PTR(gout);
+  AF_REQUIRE_PTR(src);
+  AF_REQUIRE_PTR(flow);
+  AF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && B <= 65535 && H <= 65535, ARFLOW_ESHAPE);
+  AF_REQUIRE(flow_bstride >= 2L * H * W, ARFLOW_ESHAPE);
+  AF_REQUIRE(pad_mode == ARFLOW_PAD_ZEROS || pad_mode == ARFLOW_PAD_BORDER, ARFLOW_EPARAM);
+  AF_REQUIRE(norm_mode >= ARFLOW_NORM_ARFLOW && norm_mode <= ARFLOW_NORM_UFLOW_ABS, ARFLOW_EPARAM);
+  if (!gsrc && !gflow) return ARFLOW_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (gsrc) {
+    hipError_t e = hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * C * Hs * Ws, st);
+    if (e != hipSuccess) return af_hip_status(e);
+  }
+  hipLaunchKernelGGL(warp_bicubic_bwd_kernel, dim3(af_cdiv(W, 256), H, B), dim3(256), 0, st, gout, src, flow, gsrc, gflow, C, Hs,
+                     Ws, H, W, flow_bstride, pad_mode, align_corners, norm_mode);
   return af_launch_status();
 }
 

@@ -796,6 +796,43 @@ def warp_nearest(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW):
     return WarpNearestFunction.apply(src, flow, PAD[pad], align_corners, norm)
 
 
+class WarpBicubicFunction(torch.autograd.Function):
+    """flow_warp(mode='bicubic') (utils/warp_utils.py:83-90 -> grid_sample bicubic): both gradients."""
+
+    @staticmethod
+    def forward(ctx, src, flow, pad, align_corners, norm):
+        _need_gpu(src, flow)
+        src = src.contiguous()
+        flow, fbs = _flow_view(flow)
+        B, C, Hs, Ws = src.shape
+        _, _, H, W = flow.shape
+        out = torch.empty(B, C, H, W, device=src.device, dtype=torch.float32)
+        with torch.cuda.device_of(src):
+            _call('arflow_warp_bicubic_fwd', _p(src), _p(flow), _p(out), B, C, Hs, Ws, H, W, fbs, pad, int(bool(align_corners)),
+                  norm, _stream())
+        ctx.save_for_backward(src, flow)
+        ctx.cfg = (pad, int(bool(align_corners)), norm, fbs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, flow = ctx.saved_tensors
+        pad, ac, norm, fbs = ctx.cfg
+        B, C, Hs, Ws = src.shape
+        _, _, H, W = flow.shape
+        gout = gout.contiguous()
+        gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty(B, 2, H, W, device=src.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device_of(src):
+            _call('arflow_warp_bicubic_bwd', _p(gout), _p(src), _p(flow), _p(gsrc), _p(gflow), B, C, Hs, Ws, H, W, fbs, pad, ac,
+                  norm, _stream())
+        return gsrc, gflow, None, None, None
+
+
+def warp_bicubic(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW):
+    return WarpBicubicFunction.apply(src, flow, PAD[pad], align_corners, norm)
+
+
 def warp(src, flow, pad='zeros', align_corners=True, norm=NORM_ARFLOW, storage=None):
     if _storage(storage) == 'bf16':
         return WarpBF16Function.apply(src, flow, PAD[pad], align_corners, norm)

@@ -9,8 +9,10 @@ def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True, storage
     warped source as bf16 in HBM, fp32 arithmetic / output / gradients."""
     if mode == 'nearest':
         return AF.warp_nearest(x, flow, pad=pad, align_corners=align_corners, norm=AF.NORM_ARFLOW)
+    if mode == 'bicubic':
+        return AF.warp_bicubic(x, flow, pad=pad, align_corners=align_corners, norm=AF.NORM_ARFLOW)
     if mode != 'bilinear':
-        raise NotImplementedError("mode must be 'bilinear' or 'nearest' ('bicubic' is not implemented; no caller uses it)")
+        raise ValueError("mode must be 'bilinear', 'nearest' or 'bicubic' (F.grid_sample's modes for 4-D input)")
     return AF.warp(x, flow, pad=pad, align_corners=align_corners, norm=AF.NORM_ARFLOW, storage=storage_dtype)
 
 

@@ -382,6 +382,14 @@ int arflow_warp_nearest_fwd(const float* src, const float* flow, float* out, int
                             long flow_bstride, int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream);
 int arflow_warp_nearest_bwd(const float* gout, const float* flow, float* gsrc, int B, int C, int Hs, int Ws, int H, int W,
                             long flow_bstride, int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream);
+/* flow_warp(mode='bicubic') (utils/warp_utils.py:83-90 -> grid_sample bicubic, ATen/native/GridSampler.h: A = -0.75, 4 x 4
+ * taps at bounded positions, rows first): gradients w.r.t. the source (gsrc, nullable; zero-filled by the call) and the flow
+ * (gflow, nullable).  Plain one-thread-per-pixel kernels: no shipped configuration uses this mode. */
+int arflow_warp_bicubic_fwd(const float* src, const float* flow, float* out, int B, int C, int Hs, int Ws, int H, int W,
+                            long flow_bstride, int pad_mode, int align_corners, int norm_mode, arflow_stream_t stream);
+int arflow_warp_bicubic_bwd(const float* gout, const float* src, const float* flow, float* gsrc, float* gflow, int B, int C,
+                            int Hs, int Ws, int H, int W, long flow_bstride, int pad_mode, int align_corners, int norm_mode,
+                            arflow_stream_t stream);
 /* SSIM(x, y, md) distance map of losses/loss_blocks.py:65-84 for any window (2md+1)^2, 1 <= md <= 16:
  * out [B,C,H-2md,W-2md]; arflow_ssim_bwd gives d(sum gmap*out)/dx (call with x and y swapped for d/dy: SSIM is
  * symmetric).  (md = 1 fused with the L1 term and the mask sums is arflow_photo_fwd/bwd.) */

@@ -325,7 +325,7 @@ def gen_examples():
 
 
 def gen_general():
-    """The parameter values no shipped config uses but the reference's functions accept: flow_warp(mode='nearest')
+    """The parameter values no shipped config uses but the reference's functions accept: flow_warp(mode='nearest' | 'bicubic')
     (utils/warp_utils.py:83-90), SSIM(md=2) (losses/loss_blocks.py:65-84), TernaryLoss(max_distance=4 / 5)
     (losses/loss_blocks.py:12-62) -- reference outputs and autograd gradients."""
     from utils import warp_utils
@@ -345,6 +345,11 @@ def gen_general():
                 gx, = grads(y, [xx], g)
                 tag = '%s_%s_%d' % (name, pad, int(ac))
                 out.update({tag + '_y': y, tag + '_gx': gx})
+                # mode='bicubic' (round 3): both gradients
+                xx, ff = x.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+                y = warp_utils.flow_warp(xx, ff, pad=pad, mode='bicubic', align_corners=ac)
+                gx, gf = grads(y, [xx, ff], g)
+                out.update({tag + '_cub_y': y, tag + '_cub_gx': gx, tag + '_cub_gf': gf})
     out['wnames'] = np.array([c[0] for c in wcases])
     im1, im2 = torch.rand(2, 3, 18, 23, generator=rng), torch.rand(2, 3, 18, 23, generator=rng)
     out.update({'im1': im1, 'im2': im2})

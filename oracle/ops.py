@@ -131,6 +131,46 @@ def sample_nearest(src, ix, iy, pad='zeros'):
     return v * ok.unsqueeze(1).to(src.dtype)
 
 
+def _cubic_coeffs(t):
+    """ATen/native/GridSampler.h get_cubic_upsample_coefficients (A = -0.75) -> 4 weights for taps -1, 0, +1, +2."""
+    A = -0.75
+
+    def conv1(x):
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+
+    def conv2(x):
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    return [conv2(t + 1.0), conv1(t), conv1(1.0 - t), conv2((1.0 - t) + 1.0)]
+
+
+def sample_bicubic(src, ix, iy, pad='zeros'):
+    """torch's ``grid_sample(mode='bicubic')`` after un-normalisation (ATen/native/GridSampler.h get_value_bounded,
+    ATen/native/cpu/GridSamplerKernel.cpp / cuda/GridSampler.cu bicubic branch): 4 x 4 taps around floor(coordinate), each read
+    at its BOUNDED position (border: the tap position is clipped; zeros: 0 outside), rows interpolated first, then the
+    column.  Differentiable w.r.t. the source and -- through the coefficients only -- the coordinates."""
+    B, C, H, W = src.shape
+    fx, fy = torch.floor(ix).detach(), torch.floor(iy).detach()
+    cx, cy = _cubic_coeffs(ix - fx), _cubic_coeffs(iy - fy)
+    flat = src.reshape(B, C, H * W)
+    out_shape = (B, C) + tuple(ix.shape[1:])
+
+    def tap(x, y):
+        if pad == 'border':
+            x, y = x.clamp(0, W - 1), y.clamp(0, H - 1)
+        elif pad != 'zeros':
+            raise NotImplementedError(pad)
+        ok = (x >= 0) & (x <= W - 1) & (y >= 0) & (y <= H - 1)
+        idx = (y.clamp(0, H - 1) * W + x.clamp(0, W - 1)).long().reshape(B, 1, -1)
+        v = flat.gather(2, idx.expand(B, C, idx.shape[-1])).reshape(out_shape)
+        return v * ok.unsqueeze(1).to(src.dtype)
+
+    rows = []
+    for j in range(4):
+        v = [tap(fx - 1 + i, fy - 1 + j) for i in range(4)]
+        rows.append(((v[0] * cx[0].unsqueeze(1) + v[1] * cx[1].unsqueeze(1)) + v[2] * cx[2].unsqueeze(1)) + v[3] * cx[3].unsqueeze(1))
+    return ((rows[0] * cy[0].unsqueeze(1) + rows[1] * cy[1].unsqueeze(1)) + rows[2] * cy[2].unsqueeze(1)) + rows[3] * cy[3].unsqueeze(1)
+
+
 # --------------------------------------------------------------------------------------
 # a4  flow_warp (ARFlow)
 # --------------------------------------------------------------------------------------
@@ -142,7 +182,7 @@ def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True):
     this is reproduced, not fixed.  The normalise -> un-normalise round trip is kept in the
     working precision exactly as the reference + grid_sample perform it.
     """
-    if mode not in ('bilinear', 'nearest'):
+    if mode not in ('bilinear', 'nearest', 'bicubic'):
         raise NotImplementedError(mode)
     B, _, H, W = flow.shape
     xs, ys = _pixel_grid(B, H, W, flow)
@@ -152,6 +192,8 @@ def flow_warp(x, flow, pad='zeros', mode='bilinear', align_corners=True):
     iy = _unnormalize(gy, x.shape[2], align_corners)
     if mode == 'nearest':
         return sample_nearest(x, ix, iy, pad)
+    if mode == 'bicubic':
+        return sample_bicubic(x, ix, iy, pad)
     return sample_bilinear(x, ix, iy, pad)
 
 

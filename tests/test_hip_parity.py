@@ -836,6 +836,24 @@ def test_general_parameter_space_golden(golden):
             assert_close(got_, ref_, (1e-4 * float(ref_.abs().max())) / 20, 1e-5, tag + key)
 
 
+def test_flow_warp_bicubic_vs_reference_vectors(golden):
+    """flow_warp(mode='bicubic') (utils/warp_utils.py:83-90 -> grid_sample bicubic) on the generic kernels against the
+    reference's outputs and autograd gradients (tests/golden/general.npz), both paddings and align_corners flags."""
+    from arflow_amd.warp_utils import flow_warp
+    g = golden('general')
+    for name in g['wnames']:
+        for pad in ('zeros', 'border'):
+            for ac in (True, False):
+                tag = '%s_%s_%d' % (name, pad, int(ac))
+                x, fl = cu(g[name + '_x']).requires_grad_(True), cu(g[name + '_flow']).requires_grad_(True)
+                y = flow_warp(x, fl, pad=pad, mode='bicubic', align_corners=ac)
+                mx = float(g[name + '_x'].abs().max())
+                assert_close(y, g[tag + '_cub_y'], 4e-6 * mx, 1e-5, tag + ' bicubic')
+                gx, gf = torch.autograd.grad(y, [x, fl], cu(g[name + '_g']))
+                assert_close(gx, g[tag + '_cub_gx'], 1e-5, 1e-5, tag + ' bicubic gx')
+                assert_close(gf, g[tag + '_cub_gf'], 1e-5 * (1 + float(g[tag + '_cub_gf'].abs().max())), 1e-4, tag + ' bicubic gflow')
+
+
 @pytest.mark.parametrize('cfg', [(4, 1, 4, 1, 1), (3, 3, 2, 2, 2), (20, 1, 20, 1, 2), (2, 1, 4, 1, 1), (5, 3, 4, 2, 1)],
                          ids=lambda c: 'pad%d_k%d_d%d_s%d_%d' % c)
 def test_general_correlation_parameters(oracle, cfg):

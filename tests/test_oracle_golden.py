@@ -223,7 +223,7 @@ def test_correlation_gradcheck_float64():
 
 def test_general_parameter_space_oracle_vs_reference(golden):
     """Parameter values no shipped config uses (tests/golden/general.npz, frozen from the reference):
-    flow_warp(mode='nearest'), SSIM(md=2,3), TernaryLoss(max_distance=4,5)."""
+    flow_warp(mode='nearest' | 'bicubic'), SSIM(md=2,3), TernaryLoss(max_distance=4,5)."""
     from oracle import ops as O
     g = golden('general')
     for name in g['wnames']:
@@ -235,6 +235,14 @@ def test_general_parameter_space_oracle_vs_reference(golden):
                 assert_close(y, g[tag + '_y'], 0, 0, tag)
                 gx, = torch.autograd.grad(y, [x], g[name + '_g'])
                 assert_close(gx, g[tag + '_gx'], 1e-6, 1e-6, tag + ' gx')
+                # mode='bicubic': the oracle's restatement of ATen's bicubic sampler against the reference's outputs
+                xb, fb = g[name + '_x'].clone().requires_grad_(True), g[name + '_flow'].clone().requires_grad_(True)
+                yb = O.flow_warp(xb, fb, pad=pad, mode='bicubic', align_corners=ac)
+                mx = float(g[name + '_x'].abs().max())
+                assert_close(yb, g[tag + '_cub_y'], 4e-6 * mx, 1e-5, tag + ' bicubic')
+                gxb, gfb = torch.autograd.grad(yb, [xb, fb], g[name + '_g'])
+                assert_close(gxb, g[tag + '_cub_gx'], 1e-5, 1e-5, tag + ' bicubic gx')
+                assert_close(gfb, g[tag + '_cub_gf'], 1e-5 * (1 + float(g[tag + '_cub_gf'].abs().max())), 1e-4, tag + ' bicubic gflow')
     for md in (2, 3):
         assert_close(O.ssim(g['im1'], g['im2'], md), g['ssim%d' % md], 1e-6, 1e-6, 'ssim md')
     for md, sd in ((4, True), (5, False)):
