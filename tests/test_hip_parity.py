@@ -651,6 +651,33 @@ def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, family, 
     assert torch.equal(mask3, valid)
 
 
+@pytest.mark.parametrize('size', [(1, 8, 8), (2, 12, 20), (1, 36, 68), (1, 8, 200), (1, 200, 8), (3, 64, 64), (1, 60, 124), (2, 32, 244)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_census_kernel_families_agree_on_odd_sizes(AF, size, monkeypatch):
+    """The pair-shared column kernels (census_col.hip: 61-column x 32-row tiles, halo lanes, rolled pair loop) against the
+    ordered-pair kernels (census_warp.hip) on sizes that do not divide into either tiling -- one tile, one column of tiles,
+    images narrower than a wave -- for the three patch sizes: identical mask, loss and flow gradient up to the order of the
+    48 additions per pixel."""
+    B, H, W = size
+    gen = torch.Generator().manual_seed(H * W)
+    im1, im2 = cu(torch.rand(B, 3, H, W, generator=gen)), cu(torch.rand(B, 3, H, W, generator=gen))
+    flow = cu(2.5 * torch.randn(B, 2, H, W, generator=gen))
+    occ = cu(1.6 * torch.rand(B, 1, H // 4, W // 4, generator=gen) - 0.2)
+    _, g1 = AF.down4_gray(im1)
+    _, g2 = AF.down4_gray(im2, want_small=False)
+    for patch in (3, 5, 7):
+        res = {}
+        for fam in ('1', '0'):
+            monkeypatch.setenv('ARFLOW_CENSUS_COL', fam)
+            f = flow.clone().requires_grad_(True)
+            loss, mask = AF.census_warp_loss(g1, g2, f, occ, patch)
+            g, = torch.autograd.grad(loss, [f])
+            res[fam] = (loss.detach(), mask, g)
+        assert torch.equal(res['1'][1], res['0'][1]), 'mask'
+        assert_close(res['1'][0], res['0'][0], 1e-7, 5e-6, 'loss, patch %d' % patch)
+        assert_close(res['1'][2], res['0'][2], 2e-5 * float(res['0'][2].abs().max()) + 1e-12, 1e-4, 'flow gradient, patch %d' % patch)
+
+
 @pytest.mark.parametrize('up_align', [True, False])
 @pytest.mark.parametrize('shape,pad', [((2, 8, 12, 20), 'zeros'), ((3, 32, 24, 40), 'border'), ((2, 96, 12, 20), 'zeros'), ((1, 5, 6, 10), 'zeros')],
                          ids=lambda v: str(v))
