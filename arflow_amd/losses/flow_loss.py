@@ -1,5 +1,6 @@
 """unFlowLoss (ARFlow pyramid loss) on the gfx950 kernels -- same constructor, inputs and 4-tuple
 result as losses/flow_loss.py:8-114."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -41,8 +42,46 @@ class unFlowLoss(nn.Module):
         b, _, h, w = flow.shape
         return (s[0] / float(b * 2 * h * (w - 1)) / 2.) / 2. + (s[1] / float(b * 2 * (h - 1) * w) / 2.) / 2.
 
+    pair = True  # False: the two directions one after the other (the reference's order)
+
+    def _forward_stacked(self, output, target):
+        """with_bk as ONE pass over 2B samples (first B: direction 1 -> 2, last B: direction 2 -> 1; every op on this path is
+        per sample): one area resize, one warp, one occlusion / mask resize and one smoothness launch per pyramid scale instead
+        of two -- the photometric sums stay per direction (each is divided by its own mask mean, losses/flow_loss.py:27)."""
+        cfg = self.cfg
+        B = target.shape[0]
+        imgs = torch.cat([target[:, :3], target[:, 3:]], 0)
+        warp_losses, smooth_losses = [], []
+        self.pyramid_occu_mask1, self.pyramid_occu_mask2 = [], []
+        s, m0 = 1., None
+        for i, flow in enumerate(output):
+            if cfg.w_scales[i] == 0:
+                warp_losses.append(0)
+                smooth_losses.append(0)
+                continue
+            _, _, h, w = flow.shape
+            im = F.interpolate(imgs, (h, w), mode='area')
+            f = torch.cat([flow[:, :2], flow[:, 2:]], 0)
+            rec = flow_warp(torch.roll(im, B, 0), f, pad=cfg.warp_pad)
+            if i == 0:
+                fsw = torch.roll(f, B, 0)
+                m = 1 - (get_occu_mask_backward(fsw, th=0.2) if cfg.occ_from_back else get_occu_mask_bidirection(f, fsw))
+                m0 = m
+                s = min(h, w)
+            else:
+                m = F.interpolate(m0, (h, w), mode='nearest')
+            self.pyramid_occu_mask1.append(m[:B])
+            self.pyramid_occu_mask2.append(m[B:])
+            warp_losses.append((self.loss_photomatric(im[:B], rec[:B], m[:B]) + self.loss_photomatric(im[B:], rec[B:], m[B:])) / 2.)
+            smooth_losses.append(self.loss_smooth(f, im, 1.0 / s))  # the mean over 2B samples IS the directions' average
+        warp_loss = sum(l * w for l, w in zip(warp_losses, cfg.w_scales))
+        smooth_loss = cfg.w_smooth * sum(l * w for l, w in zip(smooth_losses, cfg.w_sm_scales))
+        return warp_loss + smooth_loss, warp_loss, smooth_loss, output[0].abs().mean()
+
     def forward(self, output, target):
         cfg = self.cfg
+        if self.pair and cfg.with_bk and target.is_cuda and all(f.shape[1] == 4 for f in output):
+            return self._forward_stacked(output, target)
         im1_origin, im2_origin = target[:, :3], target[:, 3:]
         warp_losses, smooth_losses = [], []
         self.pyramid_occu_mask1, self.pyramid_occu_mask2 = [], []

@@ -651,6 +651,35 @@ def test_fused_census_warp_vs_unfused_path_and_oracle(AF, oracle, size, family, 
     assert torch.equal(mask3, valid)
 
 
+@pytest.mark.parametrize('occ_from_back', [True, False])
+def test_unflow_loss_both_directions_stacked_equals_sequential(occ_from_back):
+    """unFlowLoss with_bk: the pass over 2B stacked (pair, direction) samples (losses/flow_loss.py here, _forward_stacked)
+    against the per-direction form (the reference's order, losses/flow_loss.py:60-114): same losses, masks and flow gradients."""
+    from arflow_amd.config import AttrDict
+    from arflow_amd.losses import unFlowLoss
+    from oracle.fixture_common import synth_pair
+    gen = torch.Generator().manual_seed(33)
+    B, H, W = 3, 64, 96
+    img = synth_pair(B, H, W, gen)[0].cuda()
+    flows = [(3.0 / s) * torch.randn(B, 4, H // s, W // s, generator=gen).cuda() for s in (1, 4, 8)]
+    res = {}
+    for pair in (True, False):
+        loss = unFlowLoss(AttrDict(w_l1=0.15, w_ssim=0.85, w_ternary=0.0, warp_pad='border', with_bk=True, smooth_2nd=True,
+                                   occ_from_back=occ_from_back, alpha=10, w_smooth=75.0, w_scales=[1.0, 1.0, 1.0],
+                                   w_sm_scales=[1.0, 0.0, 0.0]))
+        loss.pair = pair
+        f = [t.clone().requires_grad_(True) for t in flows]
+        out = loss(f, img)
+        g = torch.autograd.grad(out[0], f)
+        res[pair] = ([o.detach() for o in out], g, [m.clone() for m in loss.pyramid_occu_mask1 + loss.pyramid_occu_mask2])
+    for k, n in enumerate(['total', 'warp', 'smooth', '|flow|']):
+        assert_close(res[True][0][k], res[False][0][k], 1e-7, 5e-6, 'stacked vs sequential ' + n)
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b), 'occlusion masks'
+    for a, b, n in zip(res[True][1], res[False][1], ('d flow0', 'd flow1', 'd flow2')):
+        assert_close(a, b, 1e-6 * float(b.abs().max()) + 1e-12, 1e-4, n)
+
+
 @pytest.mark.parametrize('size', [(1, 8, 8), (2, 12, 20), (1, 36, 68), (1, 8, 200), (1, 200, 8), (3, 64, 64), (1, 60, 124), (2, 32, 244)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_census_kernel_families_agree_on_odd_sizes(AF, size, monkeypatch):
