@@ -703,8 +703,9 @@ def test_census_kernel_families_agree_on_odd_sizes(AF, size, monkeypatch):
             g, = torch.autograd.grad(loss, [f])
             res[fam] = (loss.detach(), mask, g)
         assert torch.equal(res['1'][1], res['0'][1]), 'mask'
-        assert_close(res['1'][0], res['0'][0], 1e-7, 5e-6, 'loss, patch %d' % patch)
-        assert_close(res['1'][2], res['0'][2], 2e-5 * float(res['0'][2].abs().max()) + 1e-12, 1e-4, 'flow gradient, patch %d' % patch)
+        assert_close(res['1'][0], res['0'][0], 1e-7, 1.5e-6, 'loss, patch %d' % patch)  # measured 2e-7 .. 7e-7 absolute on losses of 2 .. 3
+        # measured: <= 8e-7 of max|g| (the order of the 48 additions per pixel); 10x over it
+        assert_close(res['1'][2], res['0'][2], 3e-6 * float(res['0'][2].abs().max()) + 1e-12, 5e-6, 'flow gradient, patch %d' % patch)
 
 
 @pytest.mark.parametrize('up_align', [True, False])
@@ -728,9 +729,9 @@ def test_warp_with_fused_flow_upsample_vs_oracle(AF, oracle, shape, pad, up_alig
     gx, gfl = torch.autograd.grad([out, upc], [xc, fcu], [cu(go), cu(gf)])
     mx = float(x.abs().max())
     assert_close(upc, up.detach(), 2e-6, 2e-6, 'upsampled flow')  # ATen's CPU kernel associates the 4 products differently
-    assert_close(out, ref.detach(), (2e-6 + 4 * 1.2e-7 * max(H, W)) * mx * 4, 1e-5, 'warped map')
+    assert_close(out, ref.detach(), (2e-6 + 4 * 1.2e-7 * max(H, W)) * mx, 1e-5, 'warped map')  # 2 ulp of the upsampled flow x the map's slope
     assert_close(gx, gxr, 1e-5, 1e-4, 'd src')
-    assert_close(gfl, gfr, 1e-5 * (1 + float(gfr.abs().max())), 1e-4, 'd coarse flow')
+    assert_close(gfl, gfr, 3e-6 * (1 + float(gfr.abs().max())), 3e-5, 'd coarse flow')
 
 
 @pytest.mark.parametrize('family', ['column', 'ordered'])
@@ -907,7 +908,7 @@ def test_flow_warp_bicubic_vs_reference_vectors(golden):
                 assert_close(y, g[tag + '_cub_y'], 4e-6 * mx, 1e-5, tag + ' bicubic')
                 gx, gf = torch.autograd.grad(y, [x, fl], cu(g[name + '_g']))
                 assert_close(gx, g[tag + '_cub_gx'], 1e-5, 1e-5, tag + ' bicubic gx')
-                assert_close(gf, g[tag + '_cub_gf'], 1e-5 * (1 + float(g[tag + '_cub_gf'].abs().max())), 1e-4, tag + ' bicubic gflow')
+                assert_close(gf, g[tag + '_cub_gf'], 2e-6 * (1 + float(g[tag + '_cub_gf'].abs().max())), 2e-5, tag + ' bicubic gflow')
 
 
 @pytest.mark.parametrize('cfg', [(4, 1, 4, 1, 1), (3, 3, 2, 2, 2), (20, 1, 20, 1, 2), (2, 1, 4, 1, 1), (5, 3, 4, 2, 1)],
