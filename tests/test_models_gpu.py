@@ -159,7 +159,11 @@ def _worst_rel(ga, gb, names):
 
 
 @pytest.mark.parametrize('tag,linear', [('pwclite2', True), ('pwclite2', False), ('pwclite_uflow_0', False),
-                                        ('pwclite_uflow_1', False), ('pwcflow', False)])
+                                        ('pwclite_uflow_1', False), ('pwcflow', False), ('pwcflow', True)])
+# (ADVICE r2 asked for a fixed-tolerance `linear` variant per architecture.  PWCFlow has one (1e-3, like pwclite2).  For
+#  PWCLiteUflow it cannot be held: with the conv activations removed some bias gradients nearly cancel (max|g| 2e-5 against
+#  3e-2 elsewhere) and the ORACLE twin on the GPU differs from the oracle twin on the CPU by 0.74 of that maximum -- more
+#  than the HIP path does (0.38): measured with tools-style probing in round 3, nothing a tolerance can pin.)
 def test_model_parameter_gradients_elementwise(tag, linear):
     """Whole-model backward, ELEMENT-WISE per parameter tensor: the product model on the HIP kernels against
     the same host model with the oracle ops patched in, same deterministic weights and inputs.
